@@ -1,0 +1,330 @@
+/*
+ * CPU restatement (plain C) of the reference's BN256-G1 commitment hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked/loaded by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg as the checker / reported baseline.  The product library
+ * (crypto_amd/csrc) never links, loads or calls anything in this file.
+ *
+ * PARITY STATUS: unpinned for G1 points (see oracle/bn256_ref.py header and
+ * SURVEY.md 8c): the group arithmetic of the reference is in the absent Go module
+ * github.com/cloudflare/bn256 v0.0.0-20230823183853-e5d9e5b354ab and the reference's
+ * tests hold no literal point.  This file restates the published curve
+ * (y^2 = x^3 + 3 over p, generator (1,-2)) in Jacobian coordinates, the coordinate
+ * system upstream uses, and is itself checked against the independent big-int Python
+ * restatement through tests/golden/*.json.
+ *
+ * What follows the reference line by line is the *call structure*:
+ *   orc_vector_point_scalar_mul  <- go/bp/util.go:165-175   (ScalarMult + Add loop)
+ *   orc_vector_point_mul_on_scalar <- go/bp/util.go:177-183
+ *   orc_hadamard_point_mul       <- go/bp/util.go:185-195
+ *   orc_scalar_mul_each          <- go/bp/main.go:156-159   (h1[i] = H[i]*yinvn[i])
+ *   orc_keccak256                <- go/bp/util.go:232       (iden3 keccak256.Hash)
+ * ScalarMult here is plain MSB-first double-and-add (256 doublings + ~128 additions);
+ * upstream uses a 2-dimensional GLV split (~128 doublings + <=96 additions, from memory),
+ * so this port does roughly 1.7x the group operations of the real reference per term.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef struct { uint64_t l[4]; } fp;            /* Montgomery form, little-endian limbs */
+typedef struct { fp x, y, z; } jac;              /* z == 0  <=> infinity */
+
+static const fp P_ = {{0x185cac6c5e089667ULL, 0xee5b88d120b5b59eULL,
+                       0xaa6fecb86184dc21ULL, 0x8fb501e34aa387f9ULL}};
+static const fp N_ = {{0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL,
+                       0xaa6fecb86184dc21ULL, 0x8fb501e34aa387f9ULL}};
+static const fp R2_ = {{0x9c21c3ff7e444f56ULL, 0x409ed151b2efb0c2ULL,
+                        0x0c6dc37b80fb1651ULL, 0x7c36e0e62c2380b7ULL}};
+static const fp ONE_ = {{0xe7a35393a1f76999ULL, 0x11a4772edf4a4a61ULL,
+                         0x559013479e7b23deULL, 0x704afe1cb55c7806ULL}}; /* R mod p */
+#define NP0 0x2387f9007f17daa9ULL                /* -p^-1 mod 2^64 */
+
+static int fp_is_zero(const fp *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static int fp_eq(const fp *a, const fp *b) {
+    return ((a->l[0] ^ b->l[0]) | (a->l[1] ^ b->l[1]) | (a->l[2] ^ b->l[2]) | (a->l[3] ^ b->l[3])) == 0;
+}
+static int geq(const uint64_t a[4], const uint64_t b[4]) {
+    for (int i = 3; i >= 0; i--) { if (a[i] > b[i]) return 1; if (a[i] < b[i]) return 0; }
+    return 1;
+}
+static uint64_t sub4(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - b[i] - br;
+        r[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1;
+    }
+    return br;
+}
+static uint64_t add4(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+    uint64_t c = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 s = (u128)a[i] + b[i] + c;
+        r[i] = (uint64_t)s; c = (uint64_t)(s >> 64);
+    }
+    return c;
+}
+static void fp_add(fp *r, const fp *a, const fp *b) {
+    uint64_t c = add4(r->l, a->l, b->l);
+    if (c || geq(r->l, P_.l)) sub4(r->l, r->l, P_.l);
+}
+static void fp_sub(fp *r, const fp *a, const fp *b) {
+    if (sub4(r->l, a->l, b->l)) add4(r->l, r->l, P_.l);
+}
+static void fp_neg(fp *r, const fp *a) {
+    if (fp_is_zero(a)) { *r = *a; return; }
+    sub4(r->l, P_.l, a->l);
+}
+/* CIOS Montgomery product; p has its top bit set, so t needs a sixth (carry) word. */
+static void fp_mul(fp *r, const fp *a, const fp *b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 cur = (u128)a->l[j] * b->l[i] + t[j] + c;
+            t[j] = (uint64_t)cur; c = (uint64_t)(cur >> 64);
+        }
+        u128 cur = (u128)t[4] + c;
+        t[4] = (uint64_t)cur; t[5] = (uint64_t)(cur >> 64);
+        uint64_t m = t[0] * NP0;
+        cur = (u128)m * P_.l[0] + t[0];
+        c = (uint64_t)(cur >> 64);
+        for (int j = 1; j < 4; j++) {
+            cur = (u128)m * P_.l[j] + t[j] + c;
+            t[j - 1] = (uint64_t)cur; c = (uint64_t)(cur >> 64);
+        }
+        cur = (u128)t[4] + c;
+        t[3] = (uint64_t)cur;
+        t[4] = t[5] + (uint64_t)(cur >> 64);
+    }
+    if (t[4] || geq(t, P_.l)) sub4(r->l, t, P_.l); else memcpy(r->l, t, 32);
+}
+static void fp_sqr(fp *r, const fp *a) { fp_mul(r, a, a); }
+static void fp_inv(fp *r, const fp *a) {           /* a^(p-2) */
+    uint64_t e[4]; fp two = {{2, 0, 0, 0}};
+    sub4(e, P_.l, two.l);
+    fp acc = ONE_;
+    for (int i = 255; i >= 0; i--) {
+        fp_sqr(&acc, &acc);
+        if ((e[i >> 6] >> (i & 63)) & 1) fp_mul(&acc, &acc, a);
+    }
+    *r = acc;
+}
+static int fp_from_be(fp *r, const uint8_t *b) {   /* returns 0 if value >= p */
+    fp raw;
+    for (int i = 0; i < 4; i++) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; k++) w = (w << 8) | b[(3 - i) * 8 + k];
+        raw.l[i] = w;
+    }
+    if (geq(raw.l, P_.l)) return 0;
+    fp_mul(r, &raw, &R2_);
+    return 1;
+}
+static void fp_to_be(uint8_t *b, const fp *a) {
+    fp one = {{1, 0, 0, 0}}, raw;
+    fp_mul(&raw, a, &one);
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 8; k++) b[(3 - i) * 8 + k] = (uint8_t)(raw.l[i] >> (56 - 8 * k));
+}
+
+/* ---------------------------------------------------------------- group law (Jacobian) */
+static void jac_set_inf(jac *r) { r->x = ONE_; r->y = ONE_; memset(&r->z, 0, sizeof(fp)); }
+static int jac_is_inf(const jac *a) { return fp_is_zero(&a->z); }
+
+static void jac_double(jac *r, const jac *a) {     /* dbl-2009-l, a = 0 */
+    if (jac_is_inf(a) || fp_is_zero(&a->y)) { jac_set_inf(r); return; }
+    fp A, B, C, D, E, F, t, x3, y3, z3;
+    fp_sqr(&A, &a->x); fp_sqr(&B, &a->y); fp_sqr(&C, &B);
+    fp_add(&t, &a->x, &B); fp_sqr(&t, &t); fp_sub(&t, &t, &A); fp_sub(&t, &t, &C);
+    fp_add(&D, &t, &t);
+    fp_add(&E, &A, &A); fp_add(&E, &E, &A);
+    fp_sqr(&F, &E);
+    fp_sub(&x3, &F, &D); fp_sub(&x3, &x3, &D);
+    fp_sub(&t, &D, &x3); fp_mul(&y3, &E, &t);
+    fp_add(&C, &C, &C); fp_add(&C, &C, &C); fp_add(&C, &C, &C);
+    fp_sub(&y3, &y3, &C);
+    fp_mul(&z3, &a->y, &a->z); fp_add(&z3, &z3, &z3);
+    r->x = x3; r->y = y3; r->z = z3;
+}
+static void jac_add(jac *r, const jac *a, const jac *b) {   /* general addition */
+    if (jac_is_inf(a)) { *r = *b; return; }
+    if (jac_is_inf(b)) { *r = *a; return; }
+    fp z1z1, z2z2, u1, u2, s1, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
+    fp_sqr(&z1z1, &a->z); fp_sqr(&z2z2, &b->z);
+    fp_mul(&u1, &a->x, &z2z2); fp_mul(&u2, &b->x, &z1z1);
+    fp_mul(&s1, &a->y, &b->z); fp_mul(&s1, &s1, &z2z2);
+    fp_mul(&s2, &b->y, &a->z); fp_mul(&s2, &s2, &z1z1);
+    fp_sub(&h, &u2, &u1); fp_sub(&rr, &s2, &s1);
+    if (fp_is_zero(&h)) {
+        if (fp_is_zero(&rr)) { jac_double(r, a); return; }
+        jac_set_inf(r); return;
+    }
+    fp_sqr(&hh, &h); fp_mul(&hhh, &h, &hh); fp_mul(&v, &u1, &hh);
+    fp_sqr(&x3, &rr); fp_sub(&x3, &x3, &hhh); fp_sub(&x3, &x3, &v); fp_sub(&x3, &x3, &v);
+    fp_sub(&t, &v, &x3); fp_mul(&y3, &rr, &t); fp_mul(&t, &s1, &hhh); fp_sub(&y3, &y3, &t);
+    fp_mul(&z3, &a->z, &b->z); fp_mul(&z3, &z3, &h);
+    r->x = x3; r->y = y3; r->z = z3;
+}
+static void jac_to_affine_bytes(uint8_t out[64], const jac *a) {   /* G1.Marshal() */
+    if (jac_is_inf(a)) { memset(out, 0, 64); return; }
+    fp zi, zi2, zi3, x, y;
+    fp_inv(&zi, &a->z); fp_sqr(&zi2, &zi); fp_mul(&zi3, &zi2, &zi);
+    fp_mul(&x, &a->x, &zi2); fp_mul(&y, &a->y, &zi3);
+    fp_to_be(out, &x); fp_to_be(out + 32, &y);
+}
+/* G1.Unmarshal(): 0 ok, -1 coordinate >= p, -2 not on curve.  64 zero bytes -> infinity. */
+static int jac_from_affine_bytes(jac *r, const uint8_t in[64]) {
+    int allz = 1;
+    for (int i = 0; i < 64; i++) if (in[i]) { allz = 0; break; }
+    if (!fp_from_be(&r->x, in) || !fp_from_be(&r->y, in + 32)) return -1;
+    if (allz) { jac_set_inf(r); return 0; }
+    r->z = ONE_;
+    fp y2, x3, three = {{3, 0, 0, 0}}, b;
+    fp_mul(&b, &three, &R2_);
+    fp_sqr(&y2, &r->y); fp_sqr(&x3, &r->x); fp_mul(&x3, &x3, &r->x); fp_add(&x3, &x3, &b);
+    return fp_eq(&y2, &x3) ? 0 : -2;
+}
+static void jac_scalar_mult(jac *r, const jac *a, const uint8_t k_be[32]) {  /* G1.ScalarMult */
+    jac acc; jac_set_inf(&acc);
+    for (int i = 0; i < 256; i++) {
+        jac_double(&acc, &acc);
+        if ((k_be[i >> 3] >> (7 - (i & 7))) & 1) jac_add(&acc, &acc, a);
+    }
+    *r = acc;
+}
+
+/* ---------------------------------------------------------------- exported checker API */
+int orc_check_point(const uint8_t in[64]) { jac t; return jac_from_affine_bytes(&t, in); }
+
+int orc_g1_add(uint8_t out[64], const uint8_t a[64], const uint8_t b[64]) {
+    jac A, B, R; int e;
+    if ((e = jac_from_affine_bytes(&A, a)) || (e = jac_from_affine_bytes(&B, b))) return e;
+    jac_add(&R, &A, &B); jac_to_affine_bytes(out, &R); return 0;
+}
+int orc_g1_scalar_mult(uint8_t out[64], const uint8_t a[64], const uint8_t k_be[32]) {
+    jac A, R; int e;
+    if ((e = jac_from_affine_bytes(&A, a))) return e;
+    jac_scalar_mult(&R, &A, k_be); jac_to_affine_bytes(out, &R); return 0;
+}
+/* go/bp/util.go:165-175: res = g[0]*a[0]; for i>=1: res.Add(res, g[i]*a[i]).  n >= 1. */
+int orc_vector_point_scalar_mul(uint8_t out[64], const uint8_t *g, const uint8_t *a, size_t n) {
+    if (n == 0) return -3;
+    jac res, t, gi; int e;
+    if ((e = jac_from_affine_bytes(&gi, g))) return e;
+    jac_scalar_mult(&res, &gi, a);
+    for (size_t i = 1; i < n; i++) {
+        if ((e = jac_from_affine_bytes(&gi, g + 64 * i))) return e;
+        jac_scalar_mult(&t, &gi, a + 32 * i);
+        jac_add(&res, &res, &t);
+    }
+    jac_to_affine_bytes(out, &res);
+    return 0;
+}
+/* go/bp/util.go:177-183 */
+int orc_vector_point_mul_on_scalar(uint8_t *out, const uint8_t *g, const uint8_t k_be[32], size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        int e = orc_g1_scalar_mult(out + 64 * i, g + 64 * i, k_be);
+        if (e) return e;
+    }
+    return 0;
+}
+/* go/bp/main.go:156-159 */
+int orc_scalar_mul_each(uint8_t *out, const uint8_t *g, const uint8_t *k_be, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        int e = orc_g1_scalar_mult(out + 64 * i, g + 64 * i, k_be + 32 * i);
+        if (e) return e;
+    }
+    return 0;
+}
+/* go/bp/util.go:185-195 */
+int orc_hadamard_point_mul(uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        int e = orc_g1_add(out + 64 * i, a + 64 * i, b + 64 * i);
+        if (e) return e;
+    }
+    return 0;
+}
+
+/* Synthetic workload (same definition as oracle/bn256_ref.py synth_*). */
+static uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static void synth_scalar_le(uint64_t out[4], uint64_t seed, uint64_t i) {
+    uint64_t v[4];
+    for (int j = 0; j < 4; j++) v[j] = mix64(seed + (4 * i + j + 1) * 0x9E3779B97F4A7C15ULL);
+    /* v < 2^256 < 2n, so one conditional subtraction reduces mod n */
+    if (geq(v, N_.l)) sub4(v, v, N_.l);
+    memcpy(out, v, 32);
+}
+static void le_to_be32(uint8_t *b, const uint64_t v[4]) {
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 8; k++) b[(3 - i) * 8 + k] = (uint8_t)(v[i] >> (56 - 8 * k));
+}
+void orc_synth_scalars(uint8_t *out_be, uint64_t seed, size_t first, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        uint64_t v[4]; synth_scalar_le(v, seed, first + i); le_to_be32(out_be + 32 * i, v);
+    }
+}
+void orc_synth_bases(uint8_t *out_xy, uint64_t seed, size_t first, size_t n) {
+    jac g0, r; fp two = {{2, 0, 0, 0}}, t;
+    g0.x = ONE_; fp_mul(&t, &two, &R2_); fp_neg(&g0.y, &t); g0.z = ONE_;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t v[4]; uint8_t k[32];
+        synth_scalar_le(v, seed, first + i);
+        if ((v[0] | v[1] | v[2] | v[3]) == 0) v[0] = 1;
+        le_to_be32(k, v);
+        jac_scalar_mult(&r, &g0, k);
+        jac_to_affine_bytes(out_xy + 64 * i, &r);
+    }
+}
+
+/* Keccak-256, legacy 0x01 padding (iden3 keccak256.Hash, go/bp/util.go:232). */
+static const uint64_t KRC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
+    0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+    0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static const int KROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39,
+                             41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+static uint64_t rol64(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+static void keccak_f(uint64_t s[25]) {
+    for (int rnd = 0; rnd < 24; rnd++) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; i++) s[i] ^= d[i % 5];
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++)
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(s[x + 5 * y], KROT[x + 5 * y]);
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++)
+                s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        s[0] ^= KRC[rnd];
+    }
+}
+void orc_keccak256(uint8_t out[32], const uint8_t *in, size_t len) {
+    uint64_t s[25]; uint8_t blk[136];
+    memset(s, 0, sizeof s);
+    while (1) {
+        size_t take = len < 136 ? len : 136;
+        memset(blk, 0, 136); memcpy(blk, in, take);
+        int last = take < 136;
+        if (last) { blk[take] ^= 0x01; blk[135] ^= 0x80; }
+        for (int i = 0; i < 17; i++) {
+            uint64_t w = 0;
+            for (int k = 7; k >= 0; k--) w = (w << 8) | blk[8 * i + k];
+            s[i] ^= w;
+        }
+        keccak_f(s);
+        if (last) break;
+        in += take; len -= take;
+    }
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(s[i] >> (8 * k));
+}
