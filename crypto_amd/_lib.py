@@ -1,0 +1,57 @@
+"""ctypes binding of libbn256msm.so (include/bn256msm.h).  Fails loudly if the HIP library
+is missing: there is no CPU fallback on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbn256msm.so")
+
+EXPORTS = [
+    "bn256_ctx_create", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
+    "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_multi", "bn256_scalar_mul_batch",
+    "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
+    "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m crypto_amd.build` "
+            "(hipcc --offload-arch=gfx950); crypto_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u8p, i = C.c_void_p, C.c_size_t, C.c_char_p, C.c_int
+    lib.bn256_ctx_create.argtypes = [i, C.POINTER(vp)]
+    lib.bn256_ctx_destroy.argtypes = [vp]
+    lib.bn256_ctx_destroy.restype = None
+    lib.bn256_ctx_stream.argtypes = [vp]
+    lib.bn256_ctx_stream.restype = vp
+    lib.bn256_bases_upload.argtypes = [vp, u8p, sz, i, C.POINTER(vp)]
+    lib.bn256_bases_free.argtypes = [vp, vp]
+    lib.bn256_bases_free.restype = None
+    lib.bn256_bases_len.argtypes = [vp]
+    lib.bn256_bases_len.restype = sz
+    lib.bn256_msm.argtypes = [vp, vp, sz, sz, u8p, u8p]
+    lib.bn256_msm_dev.argtypes = [vp, vp, sz, sz, vp, u8p]
+    lib.bn256_msm_multi.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p), u8p]
+    lib.bn256_scalar_mul_batch.argtypes = [vp, vp, sz, sz, u8p, i, C.POINTER(vp)]
+    lib.bn256_add_batch.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
+    lib.bn256_fold.argtypes = [vp, vp, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp)]
+    lib.bn256_bases_download.argtypes = [vp, vp, sz, sz, u8p]
+    lib.bn256_random_bases.argtypes = [vp, C.c_uint64, sz, sz, i, C.POINTER(vp)]
+    lib.bn256_random_scalars.argtypes = [vp, C.c_uint64, sz, sz, vp]
+    lib.bn256_g1_sum.argtypes = [u8p, sz, u8p]
+    lib.bn256_ctx_set_tuning.argtypes = [vp, i, i]
+    lib.bn256_last_timing.argtypes = [vp, C.POINTER(C.c_float), i]
+    lib.bn256_selftest.argtypes = [vp]
+    lib.bn256_strerror.argtypes = [i]
+    lib.bn256_strerror.restype = C.c_char_p
+    _lib = lib
+    return lib

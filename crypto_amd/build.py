@@ -1,0 +1,36 @@
+"""Builds libbn256msm.so (HIP, gfx950) in-tree.  hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbn256msm.so")
+SOURCES = ["bn256msm.hip"]
+HEADERS = ["fe29.cuh", "g1.cuh", "kernels.cuh", "host_g1.h", os.path.join("..", "..", "include", "bn256msm.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + [
+        os.path.join(CSRC, s) for s in SOURCES
+    ]
+    if verbose:
+        print("[crypto_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,568 @@
+// libbn256msm: C ABI (include/bn256msm.h) + host orchestration of the gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/bn256msm.h"
+#include "host_g1.h"
+#include "kernels.cuh"
+
+#define HIPCHK(x)                         \
+  do {                                    \
+    hipError_t e_ = (x);                  \
+    if (e_ != hipSuccess) {               \
+      ctx_note_hip(e_, __LINE__);         \
+      return BN256_EHIP;                  \
+    }                                     \
+  } while (0)
+
+static thread_local char g_hip_msg[256];
+static void ctx_note_hip(hipError_t e, int line) {
+  snprintf(g_hip_msg, sizeof g_hip_msg, "HIP error: %s (bn256msm.hip:%d)", hipGetErrorString(e), line);
+}
+
+struct bn256_bases {
+  aff_mem* d;     // [levels][n]
+  size_t n;       // points per level
+  int levels;     // 1, or W when precomputed
+  int c;          // window bits the levels were built for (0 when levels == 1)
+};
+
+enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
+       WS_PACK, WS_TMP, WS_COUNT };
+
+struct bn256_ctx {
+  int device;
+  hipStream_t stream;
+  void* ws[WS_COUNT];
+  size_t cap[WS_COUNT];
+  hipEvent_t ev[8];
+  float last_ms[7];
+  int tune_c, tune_k;
+  u32* h_pack;      // pinned
+  size_t h_pack_cap;
+  u32* d_err;
+  u32* h_err;       // pinned
+};
+
+static int ws_reserve(bn256_ctx* ctx, int which, size_t bytes) {
+  if (ctx->cap[which] >= bytes) return BN256_OK;
+  if (ctx->ws[which]) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return BN256_EHIP;
+    (void)hipFree(ctx->ws[which]);
+    ctx->ws[which] = nullptr;
+    ctx->cap[which] = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&ctx->ws[which], want);
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    return e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
+  }
+  ctx->cap[which] = want;
+  return BN256_OK;
+}
+
+static inline unsigned nblocks(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" const char* bn256_strerror(int code) {
+  switch (code) {
+    case BN256_OK: return "ok";
+    case BN256_EINVAL: return "invalid argument";
+    case BN256_ELENGTH: return "invalid length for scalar mul";
+    case BN256_ECOORD: return "bn256: coordinate exceeds modulus";
+    case BN256_ENOTONCURVE: return "bn256: malformed point";
+    case BN256_EHIP: return g_hip_msg[0] ? g_hip_msg : "HIP runtime error";
+    case BN256_ENOMEM: return "out of device memory";
+    case BN256_ETOOLARGE: return "problem too large (n * windows >= 2^31)";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
+  if (!out) return BN256_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return BN256_EINVAL;
+  HIPCHK(hipSetDevice(device));
+  bn256_ctx* ctx = new (std::nothrow) bn256_ctx();
+  if (!ctx) return BN256_ENOMEM;
+  memset(ctx, 0, sizeof *ctx);
+  ctx->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipMalloc(&ctx->d_err, 256));
+  HIPCHK(hipHostMalloc(&ctx->h_err, 256));
+  ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
+  HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
+  *out = ctx;
+  return BN256_OK;
+}
+
+extern "C" void bn256_ctx_destroy(bn256_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < WS_COUNT; i++)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->d_err) (void)hipFree(ctx->d_err);
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" void* bn256_ctx_stream(bn256_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk) {
+  if (!ctx) return BN256_EINVAL;
+  if (window_bits != 0 && (window_bits < 2 || window_bits > 22)) return BN256_EINVAL;
+  if (chunk < 0 || chunk > 65536) return BN256_EINVAL;
+  ctx->tune_c = window_bits;
+  ctx->tune_k = chunk;
+  return BN256_OK;
+}
+
+extern "C" int bn256_last_timing(bn256_ctx* ctx, float* ms, int cap) {
+  if (!ctx || !ms) return 0;
+  int k = std::min(cap, 7);
+  for (int i = 0; i < k; i++) ms[i] = ctx->last_ms[i];
+  return k;
+}
+
+static int ilog2_floor(size_t n) {
+  int r = 0;
+  while (n >>= 1) r++;
+  return r;
+}
+// window width: fixed-base tables have a single bucket set, so wide windows are cheap
+static int pick_c(const bn256_ctx* ctx, size_t n, bool precomp) {
+  if (ctx->tune_c) return ctx->tune_c;
+  int lg = ilog2_floor(n ? n : 1);
+  int c = precomp ? lg - 4 : lg - 4;
+  if (!precomp && c > 16) c = 16;
+  if (c > 20) c = 20;
+  if (c < 3) c = 3;
+  return c;
+}
+static inline int windows_for(int c) { return 255 / c + 1; }
+
+static bn256_bases* bases_alloc(size_t n, int levels, int c, int* rc) {
+  bn256_bases* b = new (std::nothrow) bn256_bases();
+  if (!b) {
+    *rc = BN256_ENOMEM;
+    return nullptr;
+  }
+  b->n = n;
+  b->levels = levels;
+  b->c = c;
+  b->d = nullptr;
+  size_t bytes = std::max<size_t>(1, n) * (size_t)levels * sizeof(aff_mem);
+  hipError_t e = hipMalloc(&b->d, bytes);
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    delete b;
+    *rc = e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
+    return nullptr;
+  }
+  *rc = BN256_OK;
+  return b;
+}
+
+static int bases_precompute(bn256_ctx* ctx, bn256_bases* b) {
+  for (int l = 1; l < b->levels; l++) {
+    hipLaunchKernelGGL(k_precompute_level, dim3(nblocks(b->n, 256)), dim3(256), 0, ctx->stream,
+                       b->d + (size_t)(l - 1) * b->n, b->d + (size_t)l * b->n, (u32)b->n, (u32)b->c);
+  }
+  HIPCHK(hipGetLastError());
+  return BN256_OK;
+}
+
+extern "C" int bn256_bases_upload(bn256_ctx* ctx, const uint8_t* xy_be, size_t n, int flags, bn256_bases** out) {
+  if (!ctx || !out || (!xy_be && n)) return BN256_EINVAL;
+  *out = nullptr;
+  if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  bool precomp = (flags & BN256_PRECOMPUTE) != 0 && n > 0;
+  int c = precomp ? pick_c(ctx, n, true) : 0;
+  int levels = precomp ? windows_for(c) : 1;
+  if (precomp && (unsigned long long)n * levels >= (1ull << 31)) return BN256_ETOOLARGE;
+  int rc;
+  bn256_bases* b = bases_alloc(n, levels, c, &rc);
+  if (!b) return rc;
+  if (n) {
+    rc = ws_reserve(ctx, WS_TMP, n * 64);
+    if (rc) { bn256_bases_free(ctx, b); return rc; }
+    hipError_t e = hipMemcpyAsync(ctx->ws[WS_TMP], xy_be, n * 64, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, b); return BN256_EHIP; }
+    hipLaunchKernelGGL(k_points_from_be, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)ctx->ws[WS_TMP], b->d, (u32)n, ctx->d_err);
+    e = hipMemcpyAsync(ctx->h_err, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, b); return BN256_EHIP; }
+    u32 err = ctx->h_err[0];
+    if (err) {
+      bn256_bases_free(ctx, b);
+      return (err & 1u) ? BN256_ECOORD : BN256_ENOTONCURVE;
+    }
+    if (precomp) {
+      rc = bases_precompute(ctx, b);
+      if (rc == BN256_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BN256_EHIP;
+      if (rc) { bn256_bases_free(ctx, b); return rc; }
+    }
+  }
+  *out = b;
+  return BN256_OK;
+}
+
+extern "C" void bn256_bases_free(bn256_ctx* ctx, bn256_bases* b) {
+  if (!b) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (b->d) (void)hipFree(b->d);
+  delete b;
+}
+
+extern "C" size_t bn256_bases_len(const bn256_bases* b) { return b ? b->n : 0; }
+
+extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be) {
+  if (!ctx || !b || (!xy_be && n)) return BN256_EINVAL;
+  if (off > b->n || n > b->n - off) return BN256_ELENGTH;
+  if (!n) return BN256_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = ws_reserve(ctx, WS_TMP, n * 64);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_points_to_be, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, b->d + off,
+                     (uint8_t*)ctx->ws[WS_TMP], (u32)n);
+  HIPCHK(hipMemcpyAsync(xy_be, ctx->ws[WS_TMP], n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return BN256_OK;
+}
+
+// ---------------------------------------------------------------------------- MSM core
+// Runs the device pipeline for one contiguous range with device-resident scalars and returns
+// the XYZZ sum as a host point.
+static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* d_scalars,
+                    hostg1::Pt* result) {
+  using namespace hostg1;
+  *result = infinity();
+  for (float& f : ctx->last_ms) f = 0.f;
+  if (n == 0) return BN256_OK;
+  const bool precomp = b->levels > 1;
+  const int c = precomp ? b->c : pick_c(ctx, n, false);
+  const int W = windows_for(c);
+  if (precomp && W != b->levels) return BN256_EINVAL;
+  const u32 nb = 1u << (c - 1);
+  const u32 nsets = precomp ? 1u : (u32)W;
+  const size_t nbt = (size_t)nb * nsets;
+  const unsigned long long entries = (unsigned long long)n * W;
+  if (entries >= (1ull << 31) || (unsigned long long)b->n * b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
+  const u32 q = (u32)(c - 1);
+
+  u32 K = ctx->tune_k ? (u32)ctx->tune_k : (u32)std::min<unsigned long long>(128, std::max<unsigned long long>(16, entries / 262144));
+  const size_t T = (size_t)((entries + K - 1) / K);
+  const u32 nscan = nblocks(nbt + 1, SCAN_TILE);
+  const size_t npack = (size_t)nsets * (q + 1);
+
+  int rc;
+  if ((rc = ws_reserve(ctx, WS_RANK, entries * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_SKEY, entries * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_SVAL, entries * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_COUNTS, (nbt + 1) * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_BLOCKSUM, (size_t)(nscan + 1) * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_BUCKETS, nbt * sizeof(xyzz_mem)))) return rc;
+  if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * T * sizeof(xyzz_mem)))) return rc;
+  if ((rc = ws_reserve(ctx, WS_PACK, npack * 32 * 4))) return rc;
+  if (npack * 32 * 4 > ctx->h_pack_cap) return BN256_EINVAL;
+
+  u32* counts = (u32*)ctx->ws[WS_COUNTS];
+  u32* offsets = (u32*)ctx->ws[WS_OFFSETS];
+  u32* rank = (u32*)ctx->ws[WS_RANK];
+  u32* skey = (u32*)ctx->ws[WS_SKEY];
+  u32* sval = (u32*)ctx->ws[WS_SVAL];
+  u32* blocksum = (u32*)ctx->ws[WS_BLOCKSUM];
+  xyzz_mem* buckets = (xyzz_mem*)ctx->ws[WS_BUCKETS];
+  xyzz_mem* partials = (xyzz_mem*)ctx->ws[WS_PARTIALS];
+  u32* d_pack = (u32*)ctx->ws[WS_PACK];
+  hipStream_t s = ctx->stream;
+
+  HIPCHK(hipEventRecord(ctx->ev[0], s));
+  HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
+  hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
+                     (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)nullptr, (u32*)nullptr,
+                     (u32*)nullptr);
+  HIPCHK(hipEventRecord(ctx->ev[1], s));
+  // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
+  hipLaunchKernelGGL(k_scan1, dim3(nscan), dim3(SCAN_BLOCK), 0, s, (const u32*)counts, offsets, (u32)(nbt + 1), blocksum);
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, blocksum, nscan, blocksum + nscan);
+  hipLaunchKernelGGL(k_scan3, dim3(nscan), dim3(SCAN_BLOCK), 0, s, offsets, (u32)(nbt + 1), (const u32*)blocksum);
+  HIPCHK(hipEventRecord(ctx->ev[2], s));
+  hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
+                     (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)offsets, skey, sval);
+  HIPCHK(hipEventRecord(ctx->ev[3], s));
+  hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)skey,
+                     (const u32*)sval, (const u32*)(offsets + nbt), K, buckets, partials);
+  HIPCHK(hipEventRecord(ctx->ev[4], s));
+  hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
+                     (const xyzz_mem*)partials);
+  HIPCHK(hipEventRecord(ctx->ev[5], s));
+  for (u32 l = 0; l < q; l++) {
+    size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
+    hipLaunchKernelGGL(k_fold, dim3(nblocks(threads, 64)), dim3(64), 0, s, buckets, nsets, nb, l);
+  }
+  hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)buckets, nsets, nb, q,
+                     d_pack);
+  HIPCHK(hipEventRecord(ctx->ev[6], s));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, npack * 32 * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (int i = 0; i < 6; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  HIPCHK(hipEventElapsedTime(&ctx->last_ms[6], ctx->ev[0], ctx->ev[6]));
+
+  // Host tail: per set S = T + sum_k 2^k G_k (Horner), then sum_w 2^(c w) S_w (Horner).
+  Pt total = infinity();
+  for (int set = (int)nsets - 1; set >= 0; set--) {
+    const u32* base = ctx->h_pack + (size_t)set * (q + 1) * 32;
+    Pt acc = infinity();
+    for (int k = (int)q - 1; k >= 0; k--) {
+      acc = dbl(acc);
+      acc = padd(acc, from_device_words(base + (size_t)(k + 1) * 32));
+    }
+    acc = padd(acc, from_device_words(base));
+    if (set != (int)nsets - 1)
+      for (int j = 0; j < c; j++) total = dbl(total);
+    total = padd(total, acc);
+  }
+  *result = total;
+  return BN256_OK;
+}
+
+static int range_check(const bn256_bases* b, size_t off, size_t n) {
+  if (off > b->n || n > b->n - off) return BN256_ELENGTH;
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
+                             uint8_t out_xy_be[64]) {
+  if (!ctx || !b || !out_xy_be || (!d_scalars_be && n)) return BN256_EINVAL;
+  int rc = range_check(b, off, n);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  hostg1::Pt r;
+  rc = msm_core(ctx, b, off, n, (const uint8_t*)d_scalars_be, &r);
+  if (rc) return rc;
+  hostg1::marshal(out_xy_be, r);
+  return BN256_OK;
+}
+
+static int msm_host_scalars(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
+                            hostg1::Pt* r) {
+  int rc = range_check(b, off, n);
+  if (rc) return rc;
+  if (n) {
+    if ((rc = ws_reserve(ctx, WS_SCALARS, n * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return msm_core(ctx, b, off, n, (const uint8_t*)ctx->ws[WS_SCALARS], r);
+}
+
+extern "C" int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
+                         uint8_t out_xy_be[64]) {
+  if (!ctx || !b || !out_xy_be || (!scalars_be && n)) return BN256_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  hostg1::Pt r;
+  int rc = msm_host_scalars(ctx, b, off, n, scalars_be, &r);
+  if (rc) return rc;
+  hostg1::marshal(out_xy_be, r);
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
+                               const uint8_t* const* scalars_be, uint8_t out_xy_be[64]) {
+  if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  hostg1::Pt total = hostg1::infinity();
+  float ms[7] = {0};
+  for (int i = 0; i < k; i++) {
+    if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
+    hostg1::Pt r;
+    int rc = msm_host_scalars(ctx, b[i], off[i], n[i], scalars_be[i], &r);
+    if (rc) return rc;
+    total = hostg1::padd(total, r);
+    for (int j = 0; j < 7; j++) ms[j] += ctx->last_ms[j];
+  }
+  for (int j = 0; j < 7; j++) ctx->last_ms[j] = ms[j];
+  hostg1::marshal(out_xy_be, total);
+  return BN256_OK;
+}
+
+// ---------------------------------------------------------------------------- element-wise
+extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
+                                      const uint8_t* scalars_be, int broadcast, bn256_bases** out) {
+  if (!ctx || !in || !out || (!scalars_be && n)) return BN256_EINVAL;
+  *out = nullptr;
+  int rc = range_check(in, off, n);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  bn256_bases* r = bases_alloc(n, 1, 0, &rc);
+  if (!r) return rc;
+  if (n) {
+    size_t sb = broadcast ? 32 : n * 32;
+    if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) { bn256_bases_free(ctx, r); return rc; }
+    hipError_t e = hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(in->d + off),
+                         (const uint8_t*)ctx->ws[WS_SCALARS], r->d, (u32)n, (u32)(broadcast != 0), 0u);
+      e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+  }
+  *out = r;
+  return BN256_OK;
+}
+
+extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn256_bases* b, size_t boff,
+                               size_t n, bn256_bases** out) {
+  if (!ctx || !a || !b || !out) return BN256_EINVAL;
+  *out = nullptr;
+  int rc = range_check(a, aoff, n);
+  if (rc) return rc;
+  if ((rc = range_check(b, boff, n))) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  bn256_bases* r = bases_alloc(n, 1, 0, &rc);
+  if (!r) return rc;
+  if (n) {
+    hipLaunchKernelGGL(k_add_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(a->d + aoff),
+                       (const aff_mem*)(b->d + boff), r->d, (u32)n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+  }
+  *out = r;
+  return BN256_OK;
+}
+
+extern "C" int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256_bases* hi, size_t hi_off,
+                          size_t stride, size_t n, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                          bn256_bases** out) {
+  if (!ctx || !lo || !hi || !out || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
+  *out = nullptr;
+  if (n) {
+    size_t span = (n - 1) * stride + 1;
+    int rc = range_check(lo, lo_off, span);
+    if (rc) return rc;
+    if ((rc = range_check(hi, hi_off, span))) return rc;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  bn256_bases* r = bases_alloc(n, 1, 0, &rc);
+  if (!r) return rc;
+  if (n) {
+    if ((rc = ws_reserve(ctx, WS_SCALARS, 64))) { bn256_bases_free(ctx, r); return rc; }
+    uint8_t* ds = (uint8_t*)ctx->ws[WS_SCALARS];
+    hipError_t e = hipMemcpyAsync(ds, s_lo_be, 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ds + 32, s_hi_be, 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
+                         (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride,
+                         (const uint8_t*)ds, (const uint8_t*)(ds + 32), r->d, (u32)n);
+      e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+  }
+  *out = r;
+  return BN256_OK;
+}
+
+// ---------------------------------------------------------------------------- synthetic
+extern "C" int bn256_random_scalars(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, void* d_out_be) {
+  if (!ctx || (!d_out_be && n)) return BN256_EINVAL;
+  if (n >= (1ull << 32)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n) {
+    hipLaunchKernelGGL(k_synth_scalars, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (uint8_t*)d_out_be,
+                       (u64)seed, (u64)first, (u32)n, 0u);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return BN256_OK;
+}
+
+extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, int flags, bn256_bases** out) {
+  if (!ctx || !out) return BN256_EINVAL;
+  *out = nullptr;
+  if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  bool precomp = (flags & BN256_PRECOMPUTE) != 0 && n > 0;
+  int c = precomp ? pick_c(ctx, n, true) : 0;
+  int levels = precomp ? windows_for(c) : 1;
+  if (precomp && (unsigned long long)n * levels >= (1ull << 31)) return BN256_ETOOLARGE;
+  int rc;
+  bn256_bases* b = bases_alloc(n, levels, c, &rc);
+  if (!b) return rc;
+  if (n) {
+    // G0 = (1, p - 2) marshalled, uploaded through the ordinary Unmarshal kernel
+    uint8_t g0[64] = {0};
+    g0[31] = 1;
+    uint64_t y[4] = {hostg1::kP[0] - 2, hostg1::kP[1], hostg1::kP[2], hostg1::kP[3]};
+    hostg1::be_store(g0 + 32, y);
+    if ((rc = ws_reserve(ctx, WS_TMP, 64 + sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, n * 32))) {
+      bn256_bases_free(ctx, b);
+      return rc;
+    }
+    uint8_t* tmp = (uint8_t*)ctx->ws[WS_TMP];
+    aff_mem* d_g0 = (aff_mem*)(tmp + 64);
+    hipError_t e = hipMemcpyAsync(tmp, g0, 64, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_points_from_be, dim3(1), dim3(256), 0, ctx->stream, (const uint8_t*)tmp, d_g0, 1u, ctx->d_err);
+      hipLaunchKernelGGL(k_synth_scalars, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
+                         (uint8_t*)ctx->ws[WS_SCALARS], (u64)seed, (u64)first, (u32)n, 1u);
+      hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
+                         (const uint8_t*)ctx->ws[WS_SCALARS], b->d, (u32)n, 0u, 1u);
+      e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, b); return BN256_EHIP; }
+    if (precomp) {
+      rc = bases_precompute(ctx, b);
+      if (rc == BN256_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BN256_EHIP;
+      if (rc) { bn256_bases_free(ctx, b); return rc; }
+    }
+  }
+  *out = b;
+  return BN256_OK;
+}
+
+extern "C" int bn256_g1_sum(const uint8_t* xy_be, size_t k, uint8_t out_xy_be[64]) {
+  if ((!xy_be && k) || !out_xy_be) return BN256_EINVAL;
+  hostg1::Pt total = hostg1::infinity();
+  for (size_t i = 0; i < k; i++) {
+    hostg1::Pt p;
+    int rc = hostg1::unmarshal(p, xy_be + 64 * i);
+    if (rc) return rc;
+    total = hostg1::padd(total, p);
+  }
+  hostg1::marshal(out_xy_be, total);
+  return BN256_OK;
+}
+
+extern "C" int bn256_selftest(bn256_ctx* ctx) {
+  if (!ctx) return BN256_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
+  const u32 n = 1u << 16;
+  hipLaunchKernelGGL(k_selftest, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, ctx->d_err, n);
+  HIPCHK(hipMemcpyAsync(ctx->h_err, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return (int)ctx->h_err[0];
+}

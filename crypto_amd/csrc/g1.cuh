@@ -1,0 +1,236 @@
+// Device group law for BN256 G1 (y^2 = x^3 + 3 over Fp), the operations the reference
+// performs through bn256.G1.Add / G1.ScalarMult (go/bp/util.go:170-172, :180, :192).
+//
+// Accumulators use XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2); bases are affine.
+// Infinity is flagged by ZZ having all limbs zero (a sentinel that is only ever written
+// explicitly: a computed ZZ is == 0 mod p only in the P == +-Q cases, which are
+// intercepted before the formulas run).
+//
+// Limb/value accounting (see fe29.cuh): every coordinate that leaves a function is
+// fe_norm'ed (lower limbs in [0,2^29)) with |X|,|Y| <= 8p and |ZZ|,|ZZZ| <= 4.2p, so all
+// fe_mul operands below have limb-magnitude products <= 2 * 2^58, and every value that
+// reaches fe_canon / fe_is_zero_mod_p is below 16p in magnitude.
+#pragma once
+#include "fe29.cuh"
+
+struct xyzz {
+  fe x, y, zz, zzz;
+};
+
+// memory images
+struct aff_mem {  // 64 B: canonical Montgomery (R = 2^261) x, y as 256-bit LE words; zeros = infinity
+  u32 x[8];
+  u32 y[8];
+};
+struct xyzz_mem {  // 144 B: four lazily-reduced 9-limb coordinates
+  i32 c[36];
+};
+
+__device__ __forceinline__ bool xyzz_is_inf(const xyzz& a) { return fe_limbs_all_zero(a.zz); }
+__device__ __forceinline__ void xyzz_set_inf(xyzz& a) {
+  a.x = fe_zero();
+  a.y = fe_zero();
+  a.zz = fe_zero();
+  a.zzz = fe_zero();
+}
+__device__ __forceinline__ void xyzz_from_affine(xyzz& a, const fe& x, const fe& y) {
+  a.x = x;
+  a.y = y;
+  a.zz = fe_one();
+  a.zzz = fe_one();
+}
+
+__device__ __forceinline__ void xyzz_store(xyzz_mem* p, const xyzz& a) {
+  int4* q = reinterpret_cast<int4*>(p->c);
+  const i32* s0 = a.x.v;
+  const i32* s1 = a.y.v;
+  const i32* s2 = a.zz.v;
+  const i32* s3 = a.zzz.v;
+  i32 t[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    t[i] = s0[i];
+    t[9 + i] = s1[i];
+    t[18 + i] = s2[i];
+    t[27 + i] = s3[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_int4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+}
+__device__ __forceinline__ void xyzz_load(xyzz& a, const xyzz_mem* p) {
+  const int4* q = reinterpret_cast<const int4*>(p->c);
+  i32 t[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    int4 v = q[i];
+    t[4 * i] = v.x;
+    t[4 * i + 1] = v.y;
+    t[4 * i + 2] = v.z;
+    t[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    a.x.v[i] = t[i];
+    a.y.v[i] = t[9 + i];
+    a.zz.v[i] = t[18 + i];
+    a.zzz.v[i] = t[27 + i];
+  }
+}
+
+// Load an affine base; returns false for the point at infinity.  neg selects -P.
+__device__ __forceinline__ bool aff_load(fe& x, fe& y, const aff_mem* p, bool neg) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  u32 wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32 wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  u32 any = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) any |= wx[i] | wy[i];
+  x = fe_unpack256(wx);
+  y = fe_unpack256(wy);
+  if (neg) y = fe_neg(y);  // limbs in (-2^29, 0]: still magnitude < 2^29
+  return any != 0;
+}
+__device__ __forceinline__ void aff_store(aff_mem* p, const fe& x_canon, const fe& y_canon) {
+  u32 wx[8], wy[8];
+  fe_pack256(wx, x_canon);
+  fe_pack256(wy, y_canon);
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(wx[0], wx[1], wx[2], wx[3]);
+  q[1] = make_uint4(wx[4], wx[5], wx[6], wx[7]);
+  q[2] = make_uint4(wy[0], wy[1], wy[2], wy[3]);
+  q[3] = make_uint4(wy[4], wy[5], wy[6], wy[7]);
+}
+__device__ __forceinline__ void aff_store_inf(aff_mem* p) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  uint4 z = make_uint4(0, 0, 0, 0);
+  q[0] = z;
+  q[1] = z;
+  q[2] = z;
+  q[3] = z;
+}
+
+// 2 * (x, y) for an affine point (mdbl-2008-s-1).  BN256 G1 has prime order, so y != 0.
+__device__ __noinline__ void xyzz_dbl_affine(xyzz& r, const fe& x, const fe& y_in) {
+  fe y = fe_norm(y_in);
+  fe yy = fe_sqr(y);
+  fe v = fe_norm(fe_small_mul(yy, 4));
+  fe t = fe_mul(y, v);
+  fe w = fe_norm(fe_add(t, t));
+  fe s = fe_mul(x, v);
+  fe m = fe_norm(fe_small_mul(fe_sqr(x), 3));
+  fe x3 = fe_norm(fe_sub(fe_sub(fe_sqr(m), s), s));
+  fe y3 = fe_norm(fe_sub(fe_mul(m, fe_sub(s, x3)), fe_mul(w, y)));
+  r.x = x3;
+  r.y = y3;
+  r.zz = v;
+  r.zzz = w;
+}
+
+// r = 2a (dbl-2008-s-1)
+__device__ __noinline__ void xyzz_dbl(xyzz& r, const xyzz& a) {
+  if (xyzz_is_inf(a)) {
+    xyzz_set_inf(r);
+    return;
+  }
+  fe yy = fe_sqr(a.y);
+  fe v = fe_norm(fe_small_mul(yy, 4));
+  fe t = fe_mul(a.y, v);
+  fe w = fe_norm(fe_add(t, t));
+  fe s = fe_mul(a.x, v);
+  fe m = fe_norm(fe_small_mul(fe_sqr(a.x), 3));
+  fe x3 = fe_norm(fe_sub(fe_sub(fe_sqr(m), s), s));
+  fe y3 = fe_norm(fe_sub(fe_mul(m, fe_sub(s, x3)), fe_mul(w, a.y)));
+  fe zz3 = fe_mul(v, a.zz);
+  fe zzz3 = fe_mul(w, a.zzz);
+  r.x = x3;
+  r.y = y3;
+  r.zz = zz3;
+  r.zzz = zzz3;
+}
+
+// Rare path of the mixed addition: U2 == X1.  Kept out of line so the hot loop stays small.
+__device__ __noinline__ void xyzz_madd_special(xyzz& acc, const fe& x2, const fe& y2, const fe& rr) {
+  if (fe_is_zero_mod_p(rr)) {
+    xyzz_dbl_affine(acc, x2, y2);  // P == Q
+  } else {
+    xyzz_set_inf(acc);  // P == -Q
+  }
+}
+
+// acc += (x2, y2), affine operand not at infinity (madd-2008-s): 8M + 2S.
+__device__ __forceinline__ void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2) {
+  if (xyzz_is_inf(acc)) {
+    xyzz_from_affine(acc, x2, fe_norm(y2));
+    return;
+  }
+  fe u2 = fe_mul(x2, acc.zz);
+  fe s2 = fe_mul(y2, acc.zzz);
+  fe h = fe_sub(u2, acc.x);
+  fe rr = fe_sub(s2, acc.y);
+  fe pp = fe_sqr(h);
+  if (__builtin_expect(fe_maybe_zero_sq(pp), 0)) {
+    if (fe_is_zero_mod_p(h)) {
+      xyzz_madd_special(acc, x2, y2, rr);
+      return;
+    }
+  }
+  fe ppp = fe_mul(h, pp);
+  fe q = fe_mul(acc.x, pp);
+  fe x3 = fe_norm(fe_sub(fe_sub(fe_sub(fe_sqr(rr), ppp), q), q));
+  fe y3 = fe_norm(fe_sub(fe_mul(rr, fe_sub(q, x3)), fe_mul(acc.y, ppp)));
+  acc.zz = fe_mul(acc.zz, pp);
+  acc.zzz = fe_mul(acc.zzz, ppp);
+  acc.x = x3;
+  acc.y = y3;
+}
+
+// r = a + b, both XYZZ (add-2008-s): 12M + 2S, all special cases.
+__device__ __noinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) {
+  if (xyzz_is_inf(a)) {
+    r = b;
+    return;
+  }
+  if (xyzz_is_inf(b)) {
+    r = a;
+    return;
+  }
+  fe u1 = fe_mul(a.x, b.zz);
+  fe u2 = fe_mul(b.x, a.zz);
+  fe s1 = fe_mul(a.y, b.zzz);
+  fe s2 = fe_mul(b.y, a.zzz);
+  fe h = fe_sub(u2, u1);
+  fe rr = fe_sub(s2, s1);
+  fe pp = fe_sqr(h);
+  if (fe_maybe_zero_sq(pp)) {
+    if (fe_is_zero_mod_p(h)) {
+      if (fe_is_zero_mod_p(rr)) {
+        xyzz_dbl(r, a);
+      } else {
+        xyzz_set_inf(r);
+      }
+      return;
+    }
+  }
+  fe ppp = fe_mul(h, pp);
+  fe q = fe_mul(u1, pp);
+  fe x3 = fe_norm(fe_sub(fe_sub(fe_sub(fe_sqr(rr), ppp), q), q));
+  fe y3 = fe_norm(fe_sub(fe_mul(rr, fe_sub(q, x3)), fe_mul(s1, ppp)));
+  fe zz3 = fe_mul(fe_mul(a.zz, b.zz), pp);
+  fe zzz3 = fe_mul(fe_mul(a.zzz, b.zzz), ppp);
+  r.x = x3;
+  r.y = y3;
+  r.zz = zz3;
+  r.zzz = zzz3;
+}
+
+// Normalise to affine; outputs canonical Montgomery limbs.  Returns false for infinity.
+__device__ __noinline__ bool xyzz_to_affine(fe& x, fe& y, const xyzz& a) {
+  if (xyzz_is_inf(a)) return false;
+  fe zi3 = fe_inv(a.zzz);          // 1 / Z^3
+  fe zi = fe_mul(a.zz, zi3);       // 1 / Z
+  fe zi2 = fe_sqr(zi);             // 1 / Z^2
+  x = fe_canon(fe_mul(a.x, zi2));
+  y = fe_canon(fe_mul(a.y, zi3));
+  return true;
+}

@@ -1,0 +1,545 @@
+// HIP kernels of the BN256 G1 MSM engine (gfx950).  Pipeline of one MSM
+// (vectorPointScalarMul, go/bp/util.go:165-175, go/bppp/util.go:178-196):
+//
+//   k_recode<false>   signed c-bit digits of every scalar + per-bucket counts (rank by atomic)
+//   k_scan1/2/3       exclusive scan of the bucket counts -> bucket offsets
+//   k_recode<true>    scatter of (bucket key, base index|sign) into bucket order (counting sort)
+//   k_accumulate      balanced segmented bucket accumulation, XYZZ mixed additions
+//   k_bucket_fix      joins the partial sums of buckets that straddle thread chunks
+//   k_fold            log-depth bucket reduction: T = sum B_b and G_k = sum_{bit k of b} B_b
+//   k_pack_results    canonical XYZZ words of T, G_0..G_{c-2} for the host Horner tail
+//
+// Element-wise companions: k_points_from_be / k_points_to_be (Unmarshal / Marshal),
+// k_precompute_level (2^c * P), k_scalar_mul (vectorPointMulOnScalar and the h1 loop,
+// go/bp/util.go:177-183, go/bp/main.go:156-159), k_add_points (hadamardPointMul,
+// go/bp/util.go:185-195), k_fold_points (generator folding, go/bp/main.go:355-356).
+#pragma once
+#include "g1.cuh"
+
+#define NOKEY 0xffffffffu
+
+// ------------------------------------------------------------------ scalars
+// group order n, 32-bit little-endian words
+__device__ __forceinline__ constexpr u32 fr_n_word(int i) {
+  constexpr u32 n[8] = {0x57ac7261u, 0x1a2ef45bu, 0xf82b3924u, 0x2e8d8e12u,
+                        0x6184dc21u, 0xaa6fecb8u, 0x4aa387f9u, 0x8fb501e3u};
+  return n[i];
+}
+__device__ __forceinline__ constexpr u32 fr_half_word(int i) {  // (n - 1) / 2
+  return (fr_n_word(i) >> 1) | (i < 7 ? (fr_n_word(i < 7 ? i + 1 : 7) << 31) : 0u);
+}
+
+// k = big-endian 32 bytes at p (16-byte aligned)
+__device__ __forceinline__ void scalar_load_be(u32 k[8], const uint8_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  k[7] = __builtin_bswap32(a.x);
+  k[6] = __builtin_bswap32(a.y);
+  k[5] = __builtin_bswap32(a.z);
+  k[4] = __builtin_bswap32(a.w);
+  k[3] = __builtin_bswap32(b.x);
+  k[2] = __builtin_bswap32(b.y);
+  k[1] = __builtin_bswap32(b.z);
+  k[0] = __builtin_bswap32(b.w);
+}
+__device__ __forceinline__ void scalar_store_be(uint8_t* p, const u32 k[8]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(__builtin_bswap32(k[7]), __builtin_bswap32(k[6]), __builtin_bswap32(k[5]),
+                    __builtin_bswap32(k[4]));
+  q[1] = make_uint4(__builtin_bswap32(k[3]), __builtin_bswap32(k[2]), __builtin_bswap32(k[1]),
+                    __builtin_bswap32(k[0]));
+}
+// r = a - b, returns borrow
+__device__ __forceinline__ u32 u256_sub(u32 r[8], const u32 a[8], const u32 b[8]) {
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 t = (u64)a[i] - b[i] - br;
+    r[i] = (u32)t;
+    br = (t >> 32) & 1;
+  }
+  return (u32)br;
+}
+// Reduce an arbitrary 256-bit scalar to the signed representative: k mod n, then if
+// k > (n-1)/2 replace by n - k and report neg (k.P = -(n-k).P).  Result < 2^255.
+__device__ __forceinline__ bool scalar_reduce_signed(u32 k[8]) {
+  u32 nn[8], hh[8], t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    nn[i] = fr_n_word(i);
+    hh[i] = fr_half_word(i);
+  }
+  u32 br = u256_sub(t, k, nn);  // k >= n  <=> no borrow
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = br ? k[i] : t[i];
+  br = u256_sub(t, hh, k);  // half < k <=> borrow
+  bool neg = br != 0;
+  u256_sub(t, nn, k);
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = neg ? t[i] : k[i];
+  return neg;
+}
+__device__ __forceinline__ u32 sel8(const u32 k[8], u32 j) {
+  u32 r = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r = (j == (u32)i) ? k[i] : r;
+  return r;
+}
+__device__ __forceinline__ u32 scalar_bits(const u32 k[8], u32 bit, u32 width) {
+  u32 j = bit >> 5, s = bit & 31;
+  u64 v = (u64)sel8(k, j) | ((u64)sel8(k, j + 1) << 32);
+  return (u32)(v >> s) & ((1u << width) - 1u);
+}
+
+// ------------------------------------------------------------------ recode / count / scatter
+// One thread per scalar.  Signed digits d_w in [-2^(c-1), 2^(c-1)], sum d_w 2^(cw) = +-k.
+// Bucket key = (window set) * nb + |d| - 1; entry value = (table index << 1) | sign.
+//   SCATTER = false: rank[w*n+i] = atomicAdd(count[key], 1)
+//   SCATTER = true : skey/sval[offsets[key] + rank] = key / value
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W,
+                                                u32 nb, u32 precomp, u32 base_off, u32 level_stride,
+                                                u32* __restrict__ counts, u32* __restrict__ rank,
+                                                const u32* __restrict__ offsets, u32* __restrict__ skey,
+                                                u32* __restrict__ sval) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 k[8];
+  scalar_load_be(k, scalars_be + (size_t)i * 32);
+  bool neg = scalar_reduce_signed(k);
+  u32 carry = 0;
+  const u32 half = 1u << (c - 1);
+  for (u32 w = 0; w < W; w++) {
+    u32 bit = w * c;
+    u32 width = (bit + c <= 256) ? c : (256 - bit);
+    u32 raw = scalar_bits(k, bit, width) + carry;
+    bool over = raw > half;
+    u32 mag = over ? ((1u << c) - raw) : raw;
+    carry = over ? 1u : 0u;
+    if (mag == 0) continue;
+    u32 sign = (over != neg) ? 1u : 0u;
+    u32 key = (precomp ? 0u : w * nb) + mag - 1u;
+    if (!SCATTER) {
+      rank[(size_t)w * n + i] = atomicAdd(&counts[key], 1u);
+    } else {
+      u32 pos = offsets[key] + rank[(size_t)w * n + i];
+      u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i;
+      skey[pos] = key;
+      sval[pos] = (tidx << 1) | sign;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ exclusive scan (3 phase)
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+#define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+
+__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& total) {
+  // lds: 256 entries
+  u32 tid = threadIdx.x;
+  lds[tid] = v;
+  __syncthreads();
+  for (u32 d = 1; d < 256; d <<= 1) {
+    u32 t = (tid >= d) ? lds[tid - d] : 0;
+    __syncthreads();
+    lds[tid] += t;
+    __syncthreads();
+  }
+  total = lds[255];
+  u32 incl = lds[tid];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const u32* __restrict__ in, u32* __restrict__ out, u32 n,
+                                                      u32* __restrict__ blocksum) {
+  __shared__ u32 lds[256];
+  u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS];
+  u32 s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    s += v[j];
+  }
+  u32 total;
+  u32 ex = block_exclusive_scan_256(s, lds, total);
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+// single block: exclusive scan of blocksum[0..nblk) in place; writes grand total to *total_out
+__global__ void __launch_bounds__(256) k_scan2(u32* __restrict__ blocksum, u32 nblk, u32* __restrict__ total_out) {
+  __shared__ u32 lds[256];
+  u32 per = (nblk + 255) / 256;
+  u32 lo = threadIdx.x * per;
+  u32 s = 0;
+  for (u32 j = 0; j < per; j++)
+    if (lo + j < nblk) s += blocksum[lo + j];
+  u32 total;
+  u32 ex = block_exclusive_scan_256(s, lds, total);
+  for (u32 j = 0; j < per; j++) {
+    if (lo + j < nblk) {
+      u32 t = blocksum[lo + j];
+      blocksum[lo + j] = ex;
+      ex += t;
+    }
+  }
+  if (threadIdx.x == 0) *total_out = total;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32 n, const u32* __restrict__ blocksum) {
+  u32 add = blocksum[blockIdx.x];
+  u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; j++)
+    if (base + j < n) out[base + j] += add;
+}
+
+// ------------------------------------------------------------------ bucket accumulation
+// Thread t owns the sorted entries [t*K, (t+1)*K).  Runs of equal key are summed with mixed
+// additions.  A run that neither continues from thread t-1 nor into thread t+1 is a complete
+// bucket; otherwise it is a partial: slot 2t if it continues from the previous thread
+// (possibly also into the next), slot 2t+1 if it only continues into the next.
+__global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ table, const u32* __restrict__ skey,
+                                                    const u32* __restrict__ sval, const u32* __restrict__ total_ptr,
+                                                    u32 K, xyzz_mem* __restrict__ buckets,
+                                                    xyzz_mem* __restrict__ partials) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 M = *total_ptr;
+  u64 start64 = (u64)t * K;
+  if (start64 >= M) return;
+  u32 start = (u32)start64;
+  u32 end = (M - start > K) ? start + K : M;
+  u32 prev_key = start > 0 ? skey[start - 1] : NOKEY;
+  u32 next_key = end < M ? skey[end] : NOKEY;
+  u32 cur = skey[start];
+  bool first = true;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  for (u32 e = start; e < end; e++) {
+    u32 key = skey[e];
+    u32 val = sval[e];
+    if (key != cur) {
+      bool head = first && (cur == prev_key);
+      xyzz_store(head ? &partials[2 * (size_t)t] : &buckets[cur], acc);
+      first = false;
+      cur = key;
+      xyzz_set_inf(acc);
+    }
+    fe x2, y2;
+    if (aff_load(x2, y2, &table[val >> 1], (val & 1u) != 0)) xyzz_madd(acc, x2, y2);
+  }
+  bool head = first && (cur == prev_key);
+  bool tail = (cur == next_key);
+  xyzz_mem* dst = head ? &partials[2 * (size_t)t] : (tail ? &partials[2 * (size_t)t + 1] : &buckets[cur]);
+  xyzz_store(dst, acc);
+}
+
+// One thread per bucket: empty buckets become infinity; buckets that straddle chunks
+// t0 < t1 are the sum of partials 2*t0+1, 2*t (t0 < t < t1), 2*t1.
+__global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offsets, u32 nbt, u32 K,
+                                                   xyzz_mem* __restrict__ buckets,
+                                                   const xyzz_mem* __restrict__ partials) {
+  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbt) return;
+  u32 lo = offsets[b], hi = offsets[b + 1];
+  xyzz acc;
+  if (lo == hi) {
+    xyzz_set_inf(acc);
+    xyzz_store(&buckets[b], acc);
+    return;
+  }
+  u32 t0 = lo / K, t1 = (hi - 1) / K;
+  if (t0 == t1) return;
+  xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
+  for (u32 t = t0 + 1; t <= t1; t++) {
+    xyzz p, r;
+    xyzz_load(p, &partials[2 * (size_t)t]);
+    xyzz_add(r, acc, p);
+    acc = r;
+  }
+  xyzz_store(&buckets[b], acc);
+}
+
+// ------------------------------------------------------------------ bucket reduction
+// sum_b (b+1) B_b = T + sum_k 2^k G_k with T = sum_b B_b, G_k = sum_{b: bit k} B_b.
+// Level l (width w = nb >> l) folds the main row [0,w) and the l rows at bases nb>>j
+// (j = 1..l) in half: B[base+i] += B[base+i+w/2].  After c-1 levels T = B[0], G_k = B[2^k].
+__global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  u32 half = (nb >> level) >> 1;
+  u32 rows = level + 1;
+  u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 per_set = (u64)rows * half;
+  if (tid >= per_set * nsets) return;
+  u32 set = (u32)(tid / per_set);
+  u32 rem = (u32)(tid % per_set);
+  u32 row = rem / half, i = rem % half;
+  u32 base = row == 0 ? 0u : (nb >> row);
+  xyzz_mem* p = buckets + (size_t)set * nb + base + i;
+  xyzz a, b, r;
+  xyzz_load(a, p);
+  xyzz_load(b, p + half);
+  xyzz_add(r, a, b);
+  xyzz_store(p, r);
+}
+
+// Canonical, non-Montgomery X,Y,ZZ,ZZZ (8 x u32 LE each) of T and G_k for the host tail.
+__global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb,
+                                                     u32 q, u32* __restrict__ out) {
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= nsets * (q + 1)) return;
+  u32 set = tid / (q + 1), j = tid % (q + 1);
+  u32 idx = j == 0 ? 0u : (1u << (j - 1));
+  xyzz a;
+  xyzz_load(a, buckets + (size_t)set * nb + idx);
+  u32* o = out + (size_t)tid * 32;
+  fe* cs[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+  bool inf = xyzz_is_inf(a);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    u32 w[8];
+    fe c = fe_canon(fe_from_mont(*cs[k]));
+    fe_pack256(w, c);
+#pragma unroll
+    for (int m = 0; m < 8; m++) o[8 * k + m] = inf ? 0u : w[m];
+  }
+}
+
+// ------------------------------------------------------------------ Marshal / Unmarshal
+// err bits: 1 coordinate >= p, 2 not on curve
+__global__ void __launch_bounds__(256) k_points_from_be(const uint8_t* __restrict__ in, aff_mem* __restrict__ out,
+                                                        u32 n, u32* __restrict__ err) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 wx[8], wy[8];
+  scalar_load_be(wx, in + (size_t)i * 64);
+  scalar_load_be(wy, in + (size_t)i * 64 + 32);
+  u32 any = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) any |= wx[j] | wy[j];
+  if (any == 0) {
+    aff_store_inf(&out[i]);
+    return;
+  }
+  if (u256_geq_p(wx) || u256_geq_p(wy)) {
+    atomicOr(err, 1u);
+    aff_store_inf(&out[i]);
+    return;
+  }
+  fe x = fe_to_mont(fe_unpack256(wx));
+  fe y = fe_to_mont(fe_unpack256(wy));
+  fe b3 = {FE_B3_LIMBS};
+  fe lhs = fe_sqr(y);
+  fe rhs = fe_add(fe_mul(fe_sqr(x), x), b3);
+  if (!fe_is_zero_mod_p(fe_sub(lhs, rhs))) {
+    atomicOr(err, 2u);
+    aff_store_inf(&out[i]);
+    return;
+  }
+  aff_store(&out[i], fe_canon(x), fe_canon(y));
+}
+__global__ void __launch_bounds__(256) k_points_to_be(const aff_mem* __restrict__ in, uint8_t* __restrict__ out,
+                                                      u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x, y;
+  u32 wx[8], wy[8];
+  if (aff_load(x, y, &in[i], false)) {
+    fe_pack256(wx, fe_canon(fe_from_mont(x)));
+    fe_pack256(wy, fe_canon(fe_from_mont(y)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; j++) wx[j] = wy[j] = 0;
+  }
+  scalar_store_be(out + (size_t)i * 64, wx);
+  scalar_store_be(out + (size_t)i * 64 + 32, wy);
+}
+
+// next[i] = 2^c * prev[i]
+__global__ void __launch_bounds__(256) k_precompute_level(const aff_mem* __restrict__ prev, aff_mem* __restrict__ next,
+                                                          u32 n, u32 c) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x, y;
+  if (!aff_load(x, y, &prev[i], false)) {
+    aff_store_inf(&next[i]);
+    return;
+  }
+  xyzz a, r;
+  xyzz_dbl_affine(a, x, y);
+  for (u32 j = 1; j < c; j++) {
+    xyzz_dbl(r, a);
+    a = r;
+  }
+  if (xyzz_to_affine(x, y, a))
+    aff_store(&next[i], x, y);
+  else
+    aff_store_inf(&next[i]);
+}
+
+// ------------------------------------------------------------------ element-wise point ops
+// acc = k * (x, y), MSB-first double-and-add on the signed representative of k.
+__device__ __noinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& y_in, u32 k[8]) {
+  bool neg = scalar_reduce_signed(k);
+  fe y = neg ? fe_neg(y_in) : y_in;
+  xyzz_set_inf(acc);
+  bool started = false;
+  for (int bit = 254; bit >= 0; bit--) {
+    if (started) {
+      xyzz r;
+      xyzz_dbl(r, acc);
+      acc = r;
+    }
+    if ((sel8(k, (u32)bit >> 5) >> (bit & 31)) & 1u) {
+      xyzz_madd(acc, x, y);
+      started = true;
+    }
+  }
+}
+
+// out[i] = s_i * in[i]   (broadcast_scalar: s_0 for all; broadcast_point: in[0] for all)
+__global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ in, const uint8_t* __restrict__ scalars_be,
+                                                    aff_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
+                                                    u32 broadcast_point) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x, y;
+  if (!aff_load(x, y, &in[broadcast_point ? 0 : i], false)) {
+    aff_store_inf(&out[i]);
+    return;
+  }
+  u32 k[8];
+  scalar_load_be(k, scalars_be + (broadcast_scalar ? 0 : (size_t)i * 32));
+  xyzz acc;
+  g1_scalar_mul(acc, x, y, k);
+  if (xyzz_to_affine(x, y, acc))
+    aff_store(&out[i], x, y);
+  else
+    aff_store_inf(&out[i]);
+}
+
+__global__ void __launch_bounds__(256) k_add_points(const aff_mem* __restrict__ a, const aff_mem* __restrict__ b,
+                                                    aff_mem* __restrict__ out, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x1, y1, x2, y2;
+  bool f1 = aff_load(x1, y1, &a[i], false);
+  bool f2 = aff_load(x2, y2, &b[i], false);
+  xyzz acc;
+  xyzz_set_inf(acc);
+  if (f1) xyzz_madd(acc, x1, y1);
+  if (f2) xyzz_madd(acc, x2, y2);
+  if (xyzz_to_affine(x1, y1, acc))
+    aff_store(&out[i], x1, y1);
+  else
+    aff_store_inf(&out[i]);
+}
+
+// out[i] = s_lo * lo[i*stride] + s_hi * hi[i*stride]
+__global__ void __launch_bounds__(256) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
+                                                     u32 stride, const uint8_t* __restrict__ s_lo_be,
+                                                     const uint8_t* __restrict__ s_hi_be, aff_mem* __restrict__ out,
+                                                     u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe x, y;
+  xyzz a, b, r;
+  xyzz_set_inf(a);
+  xyzz_set_inf(b);
+  u32 k[8];
+  if (aff_load(x, y, &lo[(size_t)i * stride], false)) {
+    scalar_load_be(k, s_lo_be);
+    g1_scalar_mul(a, x, y, k);
+  }
+  if (aff_load(x, y, &hi[(size_t)i * stride], false)) {
+    scalar_load_be(k, s_hi_be);
+    g1_scalar_mul(b, x, y, k);
+  }
+  xyzz_add(r, a, b);
+  if (xyzz_to_affine(x, y, r))
+    aff_store(&out[i], x, y);
+  else
+    aff_store_inf(&out[i]);
+}
+
+// ------------------------------------------------------------------ synthetic workload
+__device__ __forceinline__ u64 mix64(u64 z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+// element i: four mix64 words (little-endian 256-bit value), reduced mod n; zero_to_one maps 0 -> 1
+__global__ void __launch_bounds__(256) k_synth_scalars(uint8_t* __restrict__ out_be, u64 seed, u64 first, u32 n,
+                                                       u32 zero_to_one) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 e = first + i;
+  u32 k[8], t[8], nn[8];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u64 v = mix64(seed + (4 * e + j + 1) * 0x9E3779B97F4A7C15ULL);
+    k[2 * j] = (u32)v;
+    k[2 * j + 1] = (u32)(v >> 32);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) nn[j] = fr_n_word(j);
+  u32 br = u256_sub(t, k, nn);
+  u32 any = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    k[j] = br ? k[j] : t[j];
+    any |= k[j];
+  }
+  if (zero_to_one && any == 0) k[0] = 1;
+  scalar_store_be(out_be + (size_t)i * 32, k);
+}
+
+// ------------------------------------------------------------------ self test
+__global__ void __launch_bounds__(256) k_selftest(u32* __restrict__ errs, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 wa[8], wb[8], wc[8];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u64 a = mix64(0x1111 + 12ull * i + j), b = mix64(0x2222 + 12ull * i + 4 + j), c = mix64(0x3333 + 12ull * i + 8 + j);
+    wa[2 * j] = (u32)a; wa[2 * j + 1] = (u32)(a >> 32);
+    wb[2 * j] = (u32)b; wb[2 * j + 1] = (u32)(b >> 32);
+    wc[2 * j] = (u32)c; wc[2 * j + 1] = (u32)(c >> 32);
+  }
+  wa[7] &= 0x7fffffffu; wb[7] &= 0x7fffffffu; wc[7] &= 0x7fffffffu;  // < 2^255 < p
+  if (i == 0) { for (int j = 0; j < 8; j++) wa[j] = 0; }
+  if (i == 1) { for (int j = 0; j < 8; j++) wa[j] = (j == 0); }
+  fe a = fe_unpack256(wa), b = fe_unpack256(wb), c = fe_unpack256(wc);
+  u32 bad = 0;
+  // pack/unpack round trip
+  u32 w2[8];
+  fe_pack256(w2, a);
+  for (int j = 0; j < 8; j++) bad |= (w2[j] != wa[j]) ? 1u : 0u;
+  // asm multiplier == portable multiplier (compare canonical forms)
+  fe m1 = fe_canon(fe_mul(a, b)), m2 = fe_canon(fe_mul_portable(a, b));
+  for (int j = 0; j < 9; j++) bad |= (m1.v[j] != m2.v[j]) ? 2u : 0u;
+  // associativity and distributivity
+  fe l = fe_canon(fe_mul(fe_mul(a, b), c)), r = fe_canon(fe_mul(a, fe_mul(b, c)));
+  for (int j = 0; j < 9; j++) bad |= (l.v[j] != r.v[j]) ? 4u : 0u;
+  l = fe_canon(fe_mul(a, fe_norm(fe_add(b, c))));
+  r = fe_canon(fe_add(fe_mul(a, b), fe_mul(a, c)));
+  for (int j = 0; j < 9; j++) bad |= (l.v[j] != r.v[j]) ? 8u : 0u;
+  // subtraction and negative values
+  l = fe_canon(fe_mul(a, fe_norm(fe_sub(b, c))));
+  r = fe_canon(fe_sub(fe_mul(a, b), fe_mul(a, c)));
+  for (int j = 0; j < 9; j++) bad |= (l.v[j] != r.v[j]) ? 16u : 0u;
+  // inversion (b != 0 with overwhelming probability)
+  fe bm = fe_to_mont(b);
+  fe one = fe_canon(fe_mul(bm, fe_inv(bm)));
+  fe ref1 = fe_canon(fe_one());
+  for (int j = 0; j < 9; j++) bad |= (one.v[j] != ref1.v[j]) ? 32u : 0u;
+  // to/from Montgomery round trip
+  fe rt = fe_canon(fe_from_mont(fe_to_mont(c)));
+  fe cc = fe_canon(c);
+  for (int j = 0; j < 9; j++) bad |= (rt.v[j] != cc.v[j]) ? 64u : 0u;
+  if (bad) atomicOr(errs, bad);
+}

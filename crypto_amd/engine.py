@@ -1,0 +1,175 @@
+"""Python host side over the C ABI (include/bn256msm.h).
+
+Names mirror the reference's helpers (go/bp/util.go) so parity tests read like the
+reference's own code: Engine.vector_point_scalar_mul == vectorPointScalarMul, etc.
+Points are 64-byte Marshal() strings, scalars Python ints in [0, 2^256)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+from . import _lib
+
+PRECOMPUTE = 1
+INF = bytes(64)
+
+
+class BN256Error(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{msg} (code {code})")
+        self.code = code
+
+
+def scalars_to_bytes(scalars: Iterable[int]) -> bytes:
+    return b"".join(int(s).to_bytes(32, "big") for s in scalars)
+
+
+class Bases:
+    """Device-resident vector of affine G1 points (a []*bn256.G1 uploaded once)."""
+
+    def __init__(self, eng: "Engine", handle: int):
+        self.eng, self.h = eng, handle
+
+    def __len__(self) -> int:
+        return self.eng.lib.bn256_bases_len(self.h)
+
+    def download(self, off: int = 0, n: int | None = None) -> list[bytes]:
+        n = len(self) - off if n is None else n
+        buf = C.create_string_buffer(64 * max(n, 1))
+        self.eng._chk(self.eng.lib.bn256_bases_download(self.eng.ctx, self.h, off, n, buf))
+        raw = buf.raw
+        return [raw[64 * i:64 * i + 64] for i in range(n)]
+
+    def free(self) -> None:
+        if self.h:
+            self.eng.lib.bn256_bases_free(self.eng.ctx, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        ctx = C.c_void_p()
+        rc = self.lib.bn256_ctx_create(device, C.byref(ctx))
+        if rc:
+            raise BN256Error(rc, self.lib.bn256_strerror(rc).decode())
+        self.ctx = ctx
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.bn256_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _chk(self, rc: int) -> None:
+        if rc:
+            raise BN256Error(rc, self.lib.bn256_strerror(rc).decode())
+
+    # ------------------------------------------------------------------ handles
+    def upload(self, points: Sequence[bytes] | bytes, flags: int = 0) -> Bases:
+        raw = points if isinstance(points, (bytes, bytearray)) else b"".join(points)
+        if len(raw) % 64:
+            raise ValueError("points must be 64 bytes each")
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_bases_upload(self.ctx, bytes(raw), len(raw) // 64, flags, C.byref(h)))
+        return Bases(self, h)
+
+    def random_bases(self, seed: int, n: int, first: int = 0, flags: int = 0) -> Bases:
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_random_bases(self.ctx, seed, first, n, flags, C.byref(h)))
+        return Bases(self, h)
+
+    def random_scalars_into(self, seed: int, n: int, dev_ptr: int, first: int = 0) -> None:
+        self._chk(self.lib.bn256_random_scalars(self.ctx, seed, first, n, C.c_void_p(dev_ptr)))
+
+    def set_tuning(self, window_bits: int = 0, chunk: int = 0) -> None:
+        self._chk(self.lib.bn256_ctx_set_tuning(self.ctx, window_bits, chunk))
+
+    def last_timing(self) -> list[float]:
+        arr = (C.c_float * 7)()
+        k = self.lib.bn256_last_timing(self.ctx, arr, 7)
+        return [arr[i] for i in range(k)]
+
+    def stream(self) -> int:
+        return self.lib.bn256_ctx_stream(self.ctx) or 0
+
+    def selftest(self) -> int:
+        return self.lib.bn256_selftest(self.ctx)
+
+    # ------------------------------------------------------------------ the hot path
+    def msm(self, bases: Bases, scalars: Sequence[int] | bytes, off: int = 0, n: int | None = None) -> bytes:
+        raw = scalars if isinstance(scalars, (bytes, bytearray)) else scalars_to_bytes(scalars)
+        n = len(raw) // 32 if n is None else n
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm(self.ctx, bases.h, off, n, bytes(raw), out))
+        return out.raw
+
+    def msm_dev(self, bases: Bases, dev_ptr: int, n: int, off: int = 0) -> bytes:
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm_dev(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), out))
+        return out.raw
+
+    def msm_multi(self, segments: Sequence[tuple[Bases, int, Sequence[int]]]) -> bytes:
+        k = len(segments)
+        hs = (C.c_void_p * max(k, 1))(*[s[0].h for s in segments])
+        offs = (C.c_size_t * max(k, 1))(*[s[1] for s in segments])
+        raws = [scalars_to_bytes(s[2]) for s in segments]
+        ns = (C.c_size_t * max(k, 1))(*[len(r) // 32 for r in raws])
+        ptrs = (C.c_char_p * max(k, 1))(*raws)
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm_multi(self.ctx, k, hs, offs, ns, ptrs, out))
+        return out.raw
+
+    # reference-named helpers (go/bp/util.go) -----------------------------------------
+    def vector_point_scalar_mul(self, g: Bases, a: Sequence[int]) -> bytes:
+        """vectorPointScalarMul, go/bp/util.go:165-175 (length mismatch panics there)."""
+        if len(g) != len(a):
+            raise ValueError("invalid length for scalar mul")
+        return self.msm(g, a)
+
+    def vector_point_scalar_mul_bppp(self, g: Bases, a: Sequence[int]) -> bytes:
+        """go/bppp/util.go:178-196: empty g -> identity, short a zero-padded, long a truncated."""
+        n = len(g)
+        if n == 0:
+            return INF
+        a = list(a)[:n] + [0] * max(0, n - len(a))
+        return self.msm(g, a)
+
+    def vector_point_mul_on_scalar(self, g: Bases, a: int, off: int = 0, n: int | None = None) -> Bases:
+        """vectorPointMulOnScalar, go/bp/util.go:177-183."""
+        n = len(g) - off if n is None else n
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_scalar_mul_batch(self.ctx, g.h, off, n, int(a).to_bytes(32, "big"), 1, C.byref(h)))
+        return Bases(self, h)
+
+    def scalar_mul_each(self, g: Bases, a: Sequence[int], off: int = 0) -> Bases:
+        """h1[i] = H[i] * yinvn[i], go/bp/main.go:156-159."""
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_scalar_mul_batch(self.ctx, g.h, off, len(a), scalars_to_bytes(a), 0, C.byref(h)))
+        return Bases(self, h)
+
+    def hadamard_point_mul(self, a: Bases, b: Bases) -> Bases:
+        """hadamardPointMul, go/bp/util.go:185-195."""
+        if len(a) != len(b):
+            raise ValueError("invalid length for scalar mul")
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_add_batch(self.ctx, a.h, 0, b.h, 0, len(a), C.byref(h)))
+        return Bases(self, h)
+
+    def fold(self, lo: Bases, lo_off: int, hi: Bases, hi_off: int, n: int, s_lo: int, s_hi: int,
+             stride: int = 1) -> Bases:
+        """s_lo*lo[i] + s_hi*hi[i]: go/bp/main.go:355-356 fused."""
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_fold(self.ctx, lo.h, lo_off, hi.h, hi_off, stride, n,
+                                      int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"), C.byref(h)))
+        return Bases(self, h)
+
+    def g1_sum(self, pts: Sequence[bytes]) -> bytes:
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_g1_sum(b"".join(pts), len(pts), out))
+        return out.raw

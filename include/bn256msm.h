@@ -1,0 +1,118 @@
+/*
+ * libbn256msm -- C ABI of the MI355X-native multi-scalar-multiplication engine for the
+ * BN256 (cloudflare/bn256) G1 commitments of olegfomenko/crypto's Bulletproofs (go/bp) and
+ * Bulletproofs++ (go/bppp) provers.
+ *
+ * The reference has no FFI: its seam is the package-private helper set in go/bp/util.go
+ * and go/bppp/util.go, and bn256.G1 can leave its package only through Marshal() /
+ * Unmarshal().  That fixes the wire format used here:
+ *   point  = 64 bytes, affine x || y, 32-byte big-endian each, infinity = 64 zero bytes
+ *   scalar = 32 bytes big-endian (scalarTo32Byte, go/bp/util.go:209-220)
+ *
+ * Conventions: every entry point returns 0 or a negative BN256_E* code and never aborts
+ * or throws.  Output buffers are caller-allocated; handles are library-owned and freed
+ * explicitly; no caller pointer is retained after return (cgo rule).  A context is used
+ * from one thread at a time; distinct contexts are independent.  One context = one GPU
+ * (one process per GPU; partial sums of a sharded MSM are combined with bn256_g1_sum).
+ */
+#ifndef BN256MSM_H
+#define BN256MSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bn256_ctx bn256_ctx;
+typedef struct bn256_bases bn256_bases;
+
+#define BN256_OK 0
+#define BN256_EINVAL (-1)      /* null pointer / bad argument */
+#define BN256_ELENGTH (-2)     /* range outside the handle ("invalid length for scalar mul") */
+#define BN256_ECOORD (-3)      /* coordinate >= p (Unmarshal: "coordinate exceeds modulus") */
+#define BN256_ENOTONCURVE (-4) /* Unmarshal: "malformed point" */
+#define BN256_EHIP (-5)        /* HIP runtime failure */
+#define BN256_ENOMEM (-6)
+#define BN256_ETOOLARGE (-7)   /* n * windows exceeds 2^31 entries */
+
+/* bn256_bases_upload flags */
+#define BN256_PRECOMPUTE 1 /* also store 2^(c*w) * P for every window w (fixed-base MSM) */
+
+/* Opens GPU `device` (HIP ordinal).  Owns one stream and the scratch buffers. */
+int bn256_ctx_create(int device, bn256_ctx** out);
+void bn256_ctx_destroy(bn256_ctx* ctx);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+void* bn256_ctx_stream(bn256_ctx* ctx);
+
+/* Copies n affine points into HBM once (replaces the repeated traversal of []*bn256.G1
+ * in vectorPointScalarMul, go/bp/util.go:165-175).  Validates like G1.Unmarshal:
+ * coordinates < p and on the curve, or all-zero = infinity.  `xy_be` is host memory. */
+int bn256_bases_upload(bn256_ctx* ctx, const uint8_t* xy_be, size_t n, int flags, bn256_bases** out);
+void bn256_bases_free(bn256_ctx* ctx, bn256_bases* b);
+size_t bn256_bases_len(const bn256_bases* b);
+
+/* out = sum_{i<n} scalars[i] * bases[off+i]  -- vectorPointScalarMul (go/bp/util.go:165-175,
+ * go/bppp/util.go:178-196).  n = 0 gives infinity (the BP++ variant's empty case); the
+ * go/bp length panic and the BP++ pad/truncate rules live in the caller-side shim.
+ * `scalars_be` is host memory (n * 32 bytes); the _dev variant takes a device pointer. */
+int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
+              uint8_t out_xy_be[64]);
+int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
+                  uint8_t out_xy_be[64]);
+
+/* Sum of k segments (bases, off, n, scalars) -- vecCom / productCom / InnerProductH
+ * (go/bp/util.go:15-27, :96-104) and the WNLA X / R commitments (go/bppp/docs_test.go:1312-1320).
+ * Scalars are host pointers. */
+int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
+                    const uint8_t* const* scalars_be, uint8_t out_xy_be[64]);
+
+/* out_i = s_i * in[off+i] (broadcast = 0, go/bp/main.go:156-159) or s * in[off+i]
+ * (broadcast = 1, vectorPointMulOnScalar, go/bp/util.go:177-183).  Result stays on device. */
+int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
+                           const uint8_t* scalars_be, int broadcast, bn256_bases** out);
+
+/* out_i = a[aoff+i] + b[boff+i] -- hadamardPointMul (go/bp/util.go:185-195). */
+int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn256_bases* b, size_t boff,
+                    size_t n, bn256_bases** out);
+
+/* out_i = s_lo * lo[lo_off + i*stride] + s_hi * hi[hi_off + i*stride]: the generator fold of the
+ * inner-product argument (go/bp/main.go:355-356, stride 1 over halves) and of WNLA
+ * (go/bppp/docs_test.go:1325-1326, stride 2 over even/odd). */
+int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256_bases* hi, size_t hi_off,
+               size_t stride, size_t n, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+               bn256_bases** out);
+
+/* Marshal() of n points of a handle into host memory. */
+int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be);
+
+/* Deterministic synthetic generators / scalars for benchmarks, replacing points(n) /
+ * values(n) (go/bp/util.go:51-63, :81-90) at sizes where n ScalarBaseMults on the CPU are
+ * infeasible.  base_i = k_i * G0 with k_i = synth(seed, first + i) (0 -> 1); definition in
+ * DESIGN.md.  bn256_random_scalars writes n * 32 big-endian bytes to a device pointer. */
+int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, int flags, bn256_bases** out);
+int bn256_random_scalars(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, void* d_out_be);
+
+/* Host-side sum of k marshalled points (combination of per-GPU partial MSMs). */
+int bn256_g1_sum(const uint8_t* xy_be, size_t k, uint8_t out_xy_be[64]);
+
+/* Window width in bits for a given n (0 = library default heuristic) and chunk length of the
+ * bucket-accumulation kernel (0 = default).  Tuning knobs; results never depend on them. */
+int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk);
+
+/* Per-phase GPU time (ms, HIP events on the context stream) of the last bn256_msm* call:
+ * [0] recode+count  [1] scan  [2] scatter  [3] bucket accumulation  [4] partial fix-up
+ * [5] bucket reduction  [6] total device time.  Returns the number of values written. */
+int bn256_last_timing(bn256_ctx* ctx, float* ms, int cap);
+
+/* Field-arithmetic self test on the device (fe_mul inline-asm path against its portable
+ * restatement and algebraic identities).  Returns 0 when every lane agrees. */
+int bn256_selftest(bn256_ctx* ctx);
+
+const char* bn256_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN256MSM_H */

@@ -328,3 +328,42 @@ void orc_keccak256(uint8_t out[32], const uint8_t *in, size_t len) {
     for (int i = 0; i < 4; i++)
         for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(s[i] >> (8 * k));
 }
+
+/* ---- multi-threaded helpers for the tests (same per-term loop, split into chunks whose
+ * partial sums are added in order; NOT the reference's single-goroutine schedule, used only
+ * to keep 2^16-term parity checks to seconds). */
+int orc_vector_point_scalar_mul_mt(uint8_t out[64], const uint8_t *g, const uint8_t *a, size_t n, int chunks) {
+    if (n == 0 || chunks < 1) return -3;
+    if ((size_t)chunks > n) chunks = (int)n;
+    jac part[256]; int err[256];
+    if (chunks > 256) chunks = 256;
+    #pragma omp parallel for schedule(static, 1)
+    for (int c = 0; c < chunks; c++) {
+        size_t lo = n * (size_t)c / chunks, hi = n * (size_t)(c + 1) / chunks;
+        jac res, t, gi; jac_set_inf(&res); err[c] = 0;
+        for (size_t i = lo; i < hi; i++) {
+            int e = jac_from_affine_bytes(&gi, g + 64 * i);
+            if (e) { err[c] = e; break; }
+            jac_scalar_mult(&t, &gi, a + 32 * i);
+            jac_add(&res, &res, &t);
+        }
+        part[c] = res;
+    }
+    jac tot; jac_set_inf(&tot);
+    for (int c = 0; c < chunks; c++) { if (err[c]) return err[c]; jac_add(&tot, &tot, &part[c]); }
+    jac_to_affine_bytes(out, &tot);
+    return 0;
+}
+void orc_synth_bases_mt(uint8_t *out_xy, uint64_t seed, size_t first, size_t n) {
+    #pragma omp parallel for schedule(static, 64)
+    for (size_t i = 0; i < n; i++) orc_synth_bases(out_xy + 64 * i, seed, first + i, 1);
+}
+int orc_scalar_mul_each_mt(uint8_t *out, const uint8_t *g, const uint8_t *k_be, size_t n, int broadcast) {
+    int bad = 0;
+    #pragma omp parallel for schedule(static, 16)
+    for (size_t i = 0; i < n; i++) {
+        int e = orc_g1_scalar_mult(out + 64 * i, g + 64 * i, k_be + (broadcast ? 0 : 32 * i));
+        if (e) bad = e;
+    }
+    return bad;
+}

@@ -1,0 +1,99 @@
+"""ctypes loader of the C restatement (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+
+
+class OracleC:
+    def __init__(self):
+        if not os.path.exists(LIB):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+        L = self.L = C.CDLL(LIB)
+        cp, sz = C.c_char_p, C.c_size_t
+        L.orc_check_point.argtypes = [cp]
+        L.orc_g1_add.argtypes = [cp, cp, cp]
+        L.orc_g1_scalar_mult.argtypes = [cp, cp, cp]
+        L.orc_vector_point_scalar_mul.argtypes = [cp, cp, cp, sz]
+        L.orc_vector_point_scalar_mul_mt.argtypes = [cp, cp, cp, sz, C.c_int]
+        L.orc_vector_point_mul_on_scalar.argtypes = [cp, cp, cp, sz]
+        L.orc_scalar_mul_each.argtypes = [cp, cp, cp, sz]
+        L.orc_scalar_mul_each_mt.argtypes = [cp, cp, cp, sz, C.c_int]
+        L.orc_hadamard_point_mul.argtypes = [cp, cp, cp, sz]
+        L.orc_synth_scalars.argtypes = [cp, C.c_uint64, sz, sz]
+        L.orc_synth_scalars.restype = None
+        L.orc_synth_bases.argtypes = [cp, C.c_uint64, sz, sz]
+        L.orc_synth_bases.restype = None
+        L.orc_synth_bases_mt.argtypes = [cp, C.c_uint64, sz, sz]
+        L.orc_synth_bases_mt.restype = None
+        L.orc_keccak256.argtypes = [cp, cp, sz]
+        L.orc_keccak256.restype = None
+
+    def synth_bases(self, seed, n, first=0) -> bytes:
+        buf = C.create_string_buffer(64 * max(n, 1))
+        self.L.orc_synth_bases_mt(buf, seed, first, n)
+        return buf.raw[:64 * n]
+
+    def synth_scalars(self, seed, n, first=0) -> bytes:
+        buf = C.create_string_buffer(32 * max(n, 1))
+        self.L.orc_synth_scalars(buf, seed, first, n)
+        return buf.raw[:32 * n]
+
+    def msm(self, bases: bytes, scalars: bytes, mt: bool = False) -> bytes:
+        """vectorPointScalarMul (go/bp/util.go:165-175) on marshalled inputs."""
+        n = len(scalars) // 32
+        assert len(bases) == 64 * n and n >= 1
+        out = C.create_string_buffer(64)
+        rc = (self.L.orc_vector_point_scalar_mul_mt(out, bases, scalars, n, 64) if mt
+              else self.L.orc_vector_point_scalar_mul(out, bases, scalars, n))
+        if rc:
+            raise ValueError(f"oracle rc {rc}")
+        return out.raw
+
+    def scalar_mul_each(self, bases: bytes, scalars: bytes, broadcast=False) -> bytes:
+        n = len(bases) // 64
+        out = C.create_string_buffer(64 * max(n, 1))
+        rc = self.L.orc_scalar_mul_each_mt(out, bases, scalars, n, int(broadcast))
+        if rc:
+            raise ValueError(f"oracle rc {rc}")
+        return out.raw[:64 * n]
+
+    def add_each(self, a: bytes, b: bytes) -> bytes:
+        n = len(a) // 64
+        out = C.create_string_buffer(64 * max(n, 1))
+        rc = self.L.orc_hadamard_point_mul(out, a, b, n)
+        if rc:
+            raise ValueError(f"oracle rc {rc}")
+        return out.raw[:64 * n]
+
+    def add(self, a: bytes, b: bytes) -> bytes:
+        return self.add_each(a, b)
+
+    def mul(self, a: bytes, k: int) -> bytes:
+        out = C.create_string_buffer(64)
+        rc = self.L.orc_g1_scalar_mult(out, a, k.to_bytes(32, "big"))
+        if rc:
+            raise ValueError(f"oracle rc {rc}")
+        return out.raw
+
+    def check_point(self, a: bytes) -> int:
+        return self.L.orc_check_point(a)
+
+    def keccak256(self, m: bytes) -> bytes:
+        out = C.create_string_buffer(32)
+        self.L.orc_keccak256(out, m, len(m))
+        return out.raw
+
+
+def build_case(orc: OracleC, case):
+    """(bases bytes list, scalar ints) for an entry of tests/golden/cases.py."""
+    from cases import apply_edits
+    name, n, sb, ss, edits = case
+    braw = orc.synth_bases(sb, n)
+    sraw = orc.synth_scalars(ss, n)
+    bases = [braw[64 * i:64 * i + 64] for i in range(n)]
+    scalars = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(n)]
+    apply_edits(bases, scalars, edits)
+    return bases, scalars

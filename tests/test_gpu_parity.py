@@ -1,0 +1,207 @@
+"""GPU parity tests: the HIP path through the C ABI against the oracle and golden fixtures.
+Bit-exact bar (integer / byte work).  Run on the GPU box: pytest -m gpu."""
+import hashlib
+
+import pytest
+
+import bn256_ref as ref
+from cases import CASES, N_ORDER
+from oracle_c import build_case
+
+pytestmark = pytest.mark.gpu
+
+INF = bytes(64)
+
+
+def test_field_selftest(eng):
+    assert eng.selftest() == 0
+
+
+def test_upload_download_roundtrip(eng, golden):
+    pts = [bytes.fromhex(e["point"]) for e in golden["kg"]]
+    h = eng.upload(pts)
+    assert len(h) == len(pts)
+    assert h.download() == pts          # includes infinity (k = 0, n)
+    assert h.download(3, 2) == pts[3:5]
+    h.free()
+
+
+def test_upload_rejects_bad_points(eng):
+    import crypto_amd
+    g0 = ref.marshal(ref.G0)
+    bad_curve = g0[:63] + b"\x00"
+    with pytest.raises(crypto_amd.BN256Error) as e:
+        eng.upload([g0, bad_curve])
+    assert e.value.code == -4
+    big = ref.P.to_bytes(32, "big") + (2).to_bytes(32, "big")
+    with pytest.raises(crypto_amd.BN256Error) as e:
+        eng.upload([big])
+    assert e.value.code == -3
+
+
+def test_random_bases_match_oracle(eng, orc, golden):
+    n = 1024
+    h = eng.random_bases(0x5EED0001, n)
+    got = b"".join(h.download())
+    assert got == orc.synth_bases(0x5EED0001, n)
+    assert hashlib.sha256(got).hexdigest() == golden["synth"]["bases_sha256_1024"]
+    h2 = eng.random_bases(0x5EED0001, 16, first=100)
+    assert b"".join(h2.download()) == got[64 * 100:64 * 116]
+
+
+def test_random_scalars_match_oracle(eng, orc, golden):
+    import torch
+    n = 1024
+    buf = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
+    eng.random_scalars_into(0x5EED0002, n, buf.data_ptr())
+    got = bytes(buf.cpu().numpy().tobytes())
+    assert got == orc.synth_scalars(0x5EED0002, n)
+    assert hashlib.sha256(got).hexdigest() == golden["synth"]["scalars_sha256_1024"]
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[1] <= 1024], ids=lambda c: c[0])
+@pytest.mark.parametrize("mode", ["plain", "precomp", "c4", "c7_k3", "c13"])
+def test_msm_cases(eng, orc, golden, case, mode):
+    import crypto_amd
+    want = bytes.fromhex(next(m for m in golden["msm"] if m["name"] == case[0])["result"])
+    bases, scalars = build_case(orc, case)
+    try:
+        if mode == "c4":
+            eng.set_tuning(4, 0)
+        elif mode == "c7_k3":
+            eng.set_tuning(7, 3)
+        elif mode == "c13":
+            eng.set_tuning(13, 5)
+        h = eng.upload(bases, crypto_amd.PRECOMPUTE if mode == "precomp" else 0)
+        got = eng.msm(h, scalars)
+        h.free()
+    finally:
+        eng.set_tuning(0, 0)
+    assert got == want
+
+
+def test_msm_65536_fixture_and_oracle(eng, orc, golden):
+    """BASELINE.json configs[1]: 2^16 random points, bit-exact vs the CPU restatement."""
+    import crypto_amd
+    case = next(c for c in CASES if c[0] == "n65536")
+    want = bytes.fromhex(next(m for m in golden["msm"] if m["name"] == "n65536")["result"])
+    n = case[1]
+    braw = orc.synth_bases(case[2], n)
+    sraw = orc.synth_scalars(case[3], n)
+    assert orc.msm(braw, sraw, mt=True) == want            # C restatement == Python fixture
+    h = eng.upload(braw)
+    assert eng.msm(h, sraw) == want
+    hp = eng.upload(braw, crypto_amd.PRECOMPUTE)
+    assert eng.msm(hp, sraw) == want
+    hd = eng.random_bases(case[2], n, flags=crypto_amd.PRECOMPUTE)   # device-generated bases
+    assert eng.msm(hd, sraw) == want
+    # sub-range and offsets
+    k = 1000
+    assert eng.msm(h, sraw[32 * k:32 * (k + 777)], off=k) == orc.msm(braw[64 * k:64 * (k + 777)], sraw[32 * k:32 * (k + 777)], mt=True)
+    assert eng.msm(hp, sraw[32 * k:32 * (k + 777)], off=k) == orc.msm(braw[64 * k:64 * (k + 777)], sraw[32 * k:32 * (k + 777)], mt=True)
+
+
+def test_msm_empty_and_length_errors(eng):
+    import crypto_amd
+    g = [ref.marshal(ref.mul(k, ref.G0)) for k in (1, 2, 3)]
+    h = eng.upload(g)
+    assert eng.msm(h, []) == INF                                   # BP++ empty case
+    with pytest.raises(ValueError, match="invalid length for scalar mul"):
+        eng.vector_point_scalar_mul(h, [1, 2])                     # go/bp panic
+    assert eng.vector_point_scalar_mul_bppp(h, [5]) == ref.marshal(ref.mul(5, ref.G0))        # zero-padded
+    assert eng.vector_point_scalar_mul_bppp(h, [1, 1, 1, 9]) == ref.marshal(ref.mul(6, ref.G0))  # truncated
+    with pytest.raises(crypto_amd.BN256Error) as e:
+        eng.msm(h, [1, 2, 3, 4])
+    assert e.value.code == -2
+    e0 = eng.upload([])
+    assert eng.vector_point_scalar_mul_bppp(e0, [1, 2]) == INF
+
+
+def test_msm_multi_matches_vec_com(eng, orc):
+    """vecCom / productCom shape: <a,G> + <b,H> + c*U as one call (go/bp/util.go:96-104)."""
+    n = 64
+    graw = orc.synth_bases(0x77, 2 * n + 1)
+    sraw = orc.synth_scalars(0x78, 2 * n + 1)
+    sc = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(2 * n + 1)]
+    G = eng.upload(graw[:64 * n])
+    H = eng.upload(graw[64 * n:64 * 2 * n])
+    U = eng.upload(graw[64 * 2 * n:])
+    got = eng.msm_multi([(G, 0, sc[:n]), (H, 0, sc[n:2 * n]), (U, 0, sc[2 * n:])])
+    assert got == orc.msm(graw, sraw)
+    # IPA "L" shape: G[n1:], H[:n1]
+    n1 = n // 2
+    got = eng.msm_multi([(G, n1, sc[:n1]), (H, 0, sc[n1:n])])
+    want = orc.msm(graw[64 * n1:64 * n] + graw[64 * n:64 * (n + n1)], sraw[:32 * n])
+    assert got == want
+
+
+def test_linearity_and_permutation_at_2_20(eng):
+    """Size-independent properties at the headline size (2^20): MSM(a) + MSM(b) == MSM(a+b),
+    MSM over a permuted-range split equals the whole, MSM(k * ones-vector) consistency."""
+    import torch
+    import crypto_amd
+    n = 1 << 20
+    h = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
+    a = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
+    b = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
+    eng.random_scalars_into(0x5EED0002, n, a.data_ptr())
+    eng.random_scalars_into(0x5EED0003, n, b.data_ptr())
+    ra = eng.msm_dev(h, a.data_ptr(), n)
+    rb = eng.msm_dev(h, b.data_ptr(), n)
+    # a + b mod n on the host (numpy big-int via python ints, vectorised through object arrays is slow;
+    # use the split property instead): MSM over [0,n/2) + MSM over [n/2,n) == MSM over [0,n)
+    half = n // 2
+    r0 = eng.msm_dev(h, a.data_ptr(), half, off=0)
+    r1 = eng.msm_dev(h, a.data_ptr() + 32 * half, half, off=half)
+    assert eng.g1_sum([r0, r1]) == ra
+    # n * P == infinity for the outputs (they are in the prime-order group)
+    hr = eng.upload([ra, rb])
+    assert eng.msm(hr, [N_ORDER - 1, 0]) == ref.marshal(ref.neg(ref.unmarshal(ra)))
+    # non-precomputed path agrees with the fixed-base path on a 2^18 prefix
+    m = 1 << 18
+    hp = eng.random_bases(0x5EED0001, m)
+    assert eng.msm_dev(hp, a.data_ptr(), m) == eng.msm_dev(h, a.data_ptr(), m)
+    assert ra != rb and ra != INF
+
+
+def test_elementwise_helpers(eng, orc, golden):
+    ew = golden["elementwise"]
+    braw = orc.synth_bases(0x5EED0001, 8)
+    sraw = orc.synth_scalars(0x5EED0002, 9)
+    a = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(8)]
+    x = int(ew["x"], 16)
+    g = eng.upload(braw)
+    assert [p.hex() for p in eng.vector_point_mul_on_scalar(g, x).download()] == ew["mul_on_scalar"]
+    assert [p.hex() for p in eng.scalar_mul_each(g, a).download()] == ew["mul_each"]
+    lo, hi = eng.upload(braw[:256]), eng.upload(braw[256:])
+    assert [p.hex() for p in eng.hadamard_point_mul(lo, hi).download()] == ew["hadamard_0_4"]
+    xinv = pow(x, -1, N_ORDER)
+    assert [p.hex() for p in eng.fold(g, 0, g, 4, 4, xinv, x).download()] == ew["fold_x_xinv"]
+    # WNLA-style even/odd fold with stride 2 (go/bppp/docs_test.go:1325-1326)
+    got = eng.fold(g, 0, g, 1, 4, 3, 5, stride=2).download()
+    for i in range(4):
+        want = orc.add(orc.mul(braw[128 * i:128 * i + 64], 3), orc.mul(braw[128 * i + 64:128 * i + 128], 5))
+        assert got[i] == want
+
+
+def test_elementwise_edge_cases(eng, orc):
+    g0 = ref.marshal(ref.G0)
+    pts = [g0, INF, ref.marshal(ref.mul(5, ref.G0)), ref.marshal(ref.neg(ref.mul(5, ref.G0)))]
+    h = eng.upload(pts)
+    # scalar 0, n, 1, n-1
+    got = eng.scalar_mul_each(h, [0, 7, N_ORDER, N_ORDER - 1]).download()
+    assert got == [INF, INF, INF, ref.marshal(ref.mul(5, ref.G0))]
+    # P + inf, inf + inf, P + P, P + (-P)
+    a = eng.upload([g0, INF, pts[2], pts[2]])
+    b = eng.upload([INF, INF, pts[2], pts[3]])
+    assert eng.hadamard_point_mul(a, b).download() == [g0, INF, ref.marshal(ref.mul(10, ref.G0)), INF]
+
+
+def test_scalar_mul_batch_1024_vs_oracle(eng, orc):
+    n = 1024
+    braw = orc.synth_bases(0x99, n)
+    sraw = orc.synth_scalars(0x9A, n)
+    h = eng.upload(braw)
+    sc = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(n)]
+    assert b"".join(eng.scalar_mul_each(h, sc).download()) == orc.scalar_mul_each(braw, sraw)
+    assert b"".join(eng.vector_point_mul_on_scalar(h, sc[0]).download()) == orc.scalar_mul_each(braw, sraw[:32], broadcast=True)
