@@ -26,6 +26,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m crypto_amd.build` "
             "(hipcc --offload-arch=gfx950); crypto_amd has no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one process
+    # cannot both own the GPU ("No HIP GPUs are available" from whichever comes second), so when
+    # torch is importable load it first: our NEEDED libamdhip64.so.7 then binds to the copy that
+    # is already mapped.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less hosts
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, sz, u8p, i = C.c_void_p, C.c_size_t, C.c_char_p, C.c_int
     lib.bn256_ctx_create.argtypes = [i, C.POINTER(vp)]

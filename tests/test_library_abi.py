@@ -1,0 +1,66 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every symbol that
+include/bn256msm.h declares, and its host-only entry points work without a GPU."""
+import ctypes as C
+import os
+import re
+
+import bn256_ref as ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "bn256msm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bn256_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from crypto_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_strerror_and_null_arguments():
+    from crypto_amd import _lib
+    lib = _lib.load()
+    assert lib.bn256_strerror(0) == b"ok"
+    assert lib.bn256_strerror(-2) == b"invalid length for scalar mul"     # go/bp/util.go:167
+    assert lib.bn256_strerror(-4) == b"bn256: malformed point"
+    out = C.create_string_buffer(64)
+    assert lib.bn256_msm(None, None, 0, 0, None, out) == -1
+    assert lib.bn256_ctx_create(0, None) == -1
+    assert lib.bn256_last_timing(None, None, 0) == 0
+    lib.bn256_ctx_destroy(None)
+    lib.bn256_bases_free(None, None)
+    assert lib.bn256_bases_len(None) == 0
+
+
+def test_host_g1_sum_matches_oracle():
+    """bn256_g1_sum is pure host code (combination of per-GPU partial sums)."""
+    from crypto_amd import _lib
+    lib = _lib.load()
+    out = C.create_string_buffer(64)
+    ks = [5, 7, ref.N - 12, 0, 12345678901234567890]
+    pts = [ref.marshal(ref.mul(k, ref.G0)) for k in ks]
+    assert lib.bn256_g1_sum(b"".join(pts), len(pts), out) == 0
+    assert out.raw == ref.marshal(ref.mul(sum(ks) % ref.N, ref.G0))
+    assert lib.bn256_g1_sum(pts[0] + pts[0], 2, out) == 0 and out.raw == ref.marshal(ref.mul(10, ref.G0))
+    assert lib.bn256_g1_sum(pts[0] + ref.marshal(ref.neg(ref.mul(5, ref.G0))), 2, out) == 0 and out.raw == bytes(64)
+    assert lib.bn256_g1_sum(b"", 0, out) == 0 and out.raw == bytes(64)
+    bad = (1).to_bytes(32, "big") + (3).to_bytes(32, "big")
+    assert lib.bn256_g1_sum(bad, 1, out) == -4
+    assert lib.bn256_g1_sum(ref.P.to_bytes(32, "big") + bytes(32), 1, out) == -3
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from crypto_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()

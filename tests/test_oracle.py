@@ -1,0 +1,168 @@
+"""CPU tests: pin the oracle (Python + C restatements) against every known answer the
+reference's own tests hold for this path and against the committed golden vectors.
+
+Point-level parity with the Go library itself is *unpinned* (no literal point in the
+reference, cloudflare/bn256 not vendored): these tests pin (a) the group order
+and scalar-helper known answers that the reference does hold, (b) Python restatement ==
+C restatement on all fixtures, (c) algebraic cross-checks (n.P = infinity, on-curve)."""
+import hashlib
+
+import pytest
+
+import bn256_ref as ref
+from cases import CASES
+from oracle_c import build_case
+
+
+def test_group_order_pinned_by_reference_docs_test():
+    # go/bppp/docs_test.go:365 prints n-4, n-1, (n-1)/2 among the Wl*w values
+    assert ref.N - 4 == 65000549695646603732796438742359905742570406053903786389881062969044166799965
+    assert ref.N - 1 == 65000549695646603732796438742359905742570406053903786389881062969044166799968
+    assert (ref.N - 1) // 2 == 32500274847823301866398219371179952871285203026951893194940531484522083399984
+    assert ref.fsub(0, 4) == ref.N - 4
+
+
+def test_scalar_helper_known_answers():
+    # go/bp/docs_test.go:390-392: a=[4,5,10,1], b=[2,1,2,10]; the reference's comment says
+    # "4 + 5 + 20 + 10 = 39" but 4*2 = 8, so vectorMul returns 43 (the test only compares
+    # commitments, it never checks the literal)
+    assert ref.vector_mul([4, 5, 10, 1], [2, 1, 2, 10]) == 43
+    # go/bppp/util_test.go:14-22: tensor of powvector(10,2) x powvector(100,3)
+    assert ref.vector_tensor_mul(ref.powvector(10, 2), ref.powvector(100, 3)) == [1, 10, 100, 1000, 10000, 100000]
+    # go/bppp/util_test.go:10-11: pow(2,-1) == inv(2)
+    assert ref.finv(2) == (ref.N + 1) // 2
+    # pad-tolerant BP++ variants (go/bppp/util.go:143-157, :245-277)
+    assert ref.vector_mul_bppp([1, 2, 3], [4]) == 4
+    assert ref.vector_add_bppp([1], [1, 2]) == [2, 2]
+    assert ref.vector_sub_bppp([1], [1, 2]) == [0, ref.N - 2]
+    assert ref.weight_vector_mul([1, 1], [1, 1], 10) == 110
+    assert ref.reduce_vector([0, 1, 2, 3, 4]) == ([0, 2, 4], [1, 3])
+    assert ref.to_bits(11, 4) == [1, 1, 0, 1]          # go/bp/docs_test.go: bits of 11
+    assert ref.to_bits(11, 2) == [1, 1]
+    assert ref.ntharr(2, 4) == [1, 2, 4, 8]
+    assert ref.fmul(ref.invntharr(7, 3)[2], 49) == 1
+
+
+def test_curve_known_answers(golden):
+    assert ref.is_on_curve(ref.G0)
+    for e in golden["kg"]:
+        k = int(e["k"], 16)
+        pt = ref.mul(k, ref.G0)
+        assert ref.marshal(pt).hex() == e["point"]
+        assert ref.is_on_curve(pt)
+    # SURVEY.md 8a derived answers
+    assert ref.marshal(ref.mul(2, ref.G0)).hex().startswith("08fb501e34aa387f9aa6fecb86184dc21ee5b88d120b5b59e185cac6c5e08965")
+    assert ref.marshal(ref.mul(ref.N - 1, ref.G0)) == (1).to_bytes(32, "big") + (2).to_bytes(32, "big")
+    assert ref.mul(ref.N, ref.G0) is ref.INF
+    assert ref.marshal(ref.INF) == bytes(64)
+    # affine law vs Jacobian ladder
+    for k in (1, 2, 3, 77, 0xDEADBEEFCAFEBABE1234):
+        assert ref.mul_affine_slow(k, ref.G0) == ref.mul(k, ref.G0)
+    # P + (-P), P + P, inf + P
+    p5 = ref.mul(5, ref.G0)
+    assert ref.add(p5, ref.neg(p5)) is ref.INF
+    assert ref.add(p5, p5) == ref.mul(10, ref.G0)
+    assert ref.add(ref.INF, p5) == p5
+
+
+def test_unmarshal_rejects():
+    with pytest.raises(ValueError):
+        ref.unmarshal(ref.P.to_bytes(32, "big") + bytes(32))
+    with pytest.raises(ValueError):
+        ref.unmarshal((1).to_bytes(32, "big") + (3).to_bytes(32, "big"))
+    assert ref.unmarshal(bytes(64)) is ref.INF
+
+
+def test_keccak(golden, orc):
+    for e in golden["keccak256"]:
+        m = bytes.fromhex(e["msg"])
+        assert ref.keccak256(m).hex() == e["digest"]
+        assert orc.keccak256(m).hex() == e["digest"]
+    assert ref.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+
+
+def test_c_oracle_synth_matches_python(golden, orc):
+    s = golden["synth"]
+    braw = orc.synth_bases(0x5EED0001, 1024)
+    sraw = orc.synth_scalars(0x5EED0002, 1024)
+    assert [braw[64 * i:64 * i + 64].hex() for i in range(4)] == s["bases_head"]
+    assert [hex(int.from_bytes(sraw[32 * i:32 * i + 32], "big")) for i in range(4)] == s["scalars_head"]
+    assert hashlib.sha256(braw).hexdigest() == s["bases_sha256_1024"]
+    assert hashlib.sha256(sraw).hexdigest() == s["scalars_sha256_1024"]
+    assert [ref.marshal(p).hex() for p in ref.synth_bases(0x5EED0001, 2)] == s["bases_head"][:2]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_c_oracle_msm_matches_fixture(golden, orc, case):
+    fx = next(m for m in golden["msm"] if m["name"] == case[0])
+    bases, scalars = build_case(orc, case)
+    sraw = b"".join(s.to_bytes(32, "big") for s in scalars)
+    assert hashlib.sha256(b"".join(bases) + sraw).hexdigest() == fx["inputs_sha256"]
+    got = orc.msm(b"".join(bases), sraw, mt=case[1] > 1024)
+    assert got.hex() == fx["result"]
+    assert orc.check_point(got) == 0
+    if case[1] <= 64:   # python reference loop, directly
+        pts = [ref.unmarshal(b) for b in bases]
+        assert ref.marshal(ref.vector_point_scalar_mul(pts, scalars)) == got
+
+
+def test_c_oracle_elementwise(golden, orc):
+    ew = golden["elementwise"]
+    braw = orc.synth_bases(0x5EED0001, 8)
+    sraw = orc.synth_scalars(0x5EED0002, 9)
+    x = int(ew["x"], 16)
+    assert int.from_bytes(sraw[256:288], "big") == x
+    got = orc.scalar_mul_each(braw, x.to_bytes(32, "big"), broadcast=True)
+    assert [got[64 * i:64 * i + 64].hex() for i in range(8)] == ew["mul_on_scalar"]
+    got = orc.scalar_mul_each(braw, sraw[:256])
+    assert [got[64 * i:64 * i + 64].hex() for i in range(8)] == ew["mul_each"]
+    got = orc.add_each(braw[:256], braw[256:])
+    assert [got[64 * i:64 * i + 64].hex() for i in range(4)] == ew["hadamard_0_4"]
+
+
+def test_reference_semantics_of_vector_point_scalar_mul():
+    g = [ref.mul(k, ref.G0) for k in (1, 2, 3)]
+    with pytest.raises(ValueError, match="invalid length for scalar mul"):   # go/bp/util.go:166-168
+        ref.vector_point_scalar_mul(g, [1, 2])
+    assert ref.vector_point_scalar_mul_bppp([], [1]) is ref.INF               # go/bppp/util.go:179-181
+    assert ref.vector_point_scalar_mul_bppp(g, [5]) == ref.mul(5, ref.G0)     # :183-185 zero pad
+    assert ref.vector_point_scalar_mul_bppp(g, [1, 1, 1, 9]) == ref.mul(6, ref.G0)  # :187-192 truncation
+    assert ref.vector_points_add_bppp(g[:1], g[:2]) == [ref.mul(2, ref.G0), g[1]]
+
+
+def test_bulletproof_transcripts(golden):
+    """Deterministic replay: same injected byte stream -> same transcript, and
+    Verify accepts; a tampered proof is rejected with the reference's error strings."""
+    for t in golden["bulletproofs"][:2]:      # N = 4, 8 (N = 64 is replayed in the GPU suite)
+        rd = ref.ByteStream(int(t["seed"], 16))
+        pub = ref.BulletProofPublic.new(rd, t["n"])
+        assert [ref.marshal(p).hex() for p in pub.inner.G] == t["G"]
+        assert ref.marshal(pub.H).hex() == t["h"]
+        prv = ref.rand_int(rd)
+        assert hex(prv) == t["prv"]
+        pr = ref.bp_prove(pub, t["v"], prv, rd)
+        assert ref.marshal(pr["A"]).hex() == t["proof"]["A"]
+        assert [ref.marshal(p).hex() for p in pr["L"]] == t["proof"]["L"]
+        assert hex(pr["a"]) == t["proof"]["a"] and hex(pr["tx"]) == t["proof"]["tx"]
+        assert ref.bp_verify(pub, pr) is None
+        bad = dict(pr)
+        bad["tx"] = ref.fadd(pr["tx"], 1)
+        assert ref.bp_verify(pub, bad) == "failed: tx ?= t0 + t1*x +t2*x^2"
+        bad = dict(pr)
+        bad["a"] = ref.fadd(pr["a"], 1)
+        assert ref.bp_verify(pub, bad) == "failed to verify inner argument proof"
+
+
+def test_inner_product_argument_walkthrough_inputs():
+    # go/bp/docs_test.go:381-392 inputs: a=[4,5,10,1], b=[2,1,2,10]; TestInnerProduct's n=8/len-4
+    # mismatch panics in the reference, so the counterpart uses n = 4.
+    rd = ref.ByteStream(0x1AA)
+    pub = ref.InnerArgumentPublic.new(rd, 4)
+    a, b = [4, 5, 10, 1], [2, 1, 2, 10]
+    L, R, fa, fb, Pm = ref.inner_arg_proof(pub, a, b)
+    assert len(L) == 2 and len(R) == 2
+    assert ref.inner_arg_verify(pub, Pm, L, R, fa, fb) is None
+    with pytest.raises(ValueError, match="invalid length"):
+        ref.vector_mul(a[:2], b)
+    assert ref.inner_arg_verify(ref.InnerArgumentPublic(3, pub.G[:3], pub.H[:3], pub.U), Pm, L, R, fa, fb) \
+        == "invalid n: should be 2^x"
