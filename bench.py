@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BN256 G1 multi-scalar multiplication (the reference's
+vectorPointScalarMul, go/bp/util.go:165-175) on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W] [--log2n 20]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete MSM: every rank runs the device pipeline on its contiguous slice of
+2^log2n points (bases resident in HBM with their fixed-base table, scalars resident in HBM
+when the timed region starts), the 64-byte partial sums are exchanged with one RCCL
+all_gather, and every rank adds them on the host.  value = total points / second.
+Weak scaling: the per-GPU slice is fixed (2^20 by default = BASELINE.json configs[2]); with
+--log2n 21 --gpus 8 the job is exactly configs[4] (2^24 points over 8 GPUs).
+
+Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for the roofline accounting.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMAD_PER_POINT = 23120          # 17 windows x 10 modmul x 136 IMAD
+IMAD_PEAK = 3.47e13             # measured v_mad_u64_u32 lane-ops/s, profiles/r01_ubench_valu.txt
+SEED_BASES, SEED_SCALARS = 0x5EED0001, 0x5EED0002
+
+
+def cpu_baseline(sample_terms: int):
+    """Reference algorithm (per-term double-and-add, then add), C restatement, 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_c import OracleC
+    orc = OracleC()
+    bases = orc.synth_bases(SEED_BASES, sample_terms)
+    scalars = orc.synth_scalars(SEED_SCALARS, sample_terms)
+    t0 = time.perf_counter()
+    out = orc.msm(bases, scalars, mt=False)
+    dt = time.perf_counter() - t0
+    return sample_terms / dt, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-precompute", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 15)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import crypto_amd
+    eng = crypto_amd.Engine(local_rank)
+    eng.set_tuning(args.window_bits, args.chunk)
+    n = 1 << args.log2n
+    first = rank * n
+    flags = 0 if args.no_precompute else crypto_amd.PRECOMPUTE
+    t0 = time.perf_counter()
+    bases = eng.random_bases(SEED_BASES, n, first=first, flags=flags)
+    setup_s = time.perf_counter() - t0
+    scalars = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+    eng.random_scalars_into(SEED_SCALARS, n, scalars.data_ptr(), first=first)
+    part = torch.zeros(64, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(64 * world, dtype=torch.uint8, device=dev)
+
+    def step():
+        p = eng.msm_dev(bases, scalars.data_ptr(), n)
+        if world == 1:
+            return p
+        part.copy_(torch.frombuffer(bytearray(p), dtype=torch.uint8))
+        dist.all_gather_into_tensor(gathered, part)
+        raw = bytes(gathered.cpu().numpy().tobytes())
+        return eng.g1_sum([raw[64 * i:64 * i + 64] for i in range(world)])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    sync()
+    acc_ms, phase = 0.0, [0.0] * 7
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        tm = eng.last_timing()
+        phase = [a + b for a, b in zip(phase, tm)]
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        phase = [p / steps for p in phase]
+        acc_s = phase[3] * 1e-3
+        achieved = n * IMAD_PER_POINT / acc_s if acc_s > 0 else 0.0
+        line = {
+            "metric": "MSM points/sec (BN256 G1, bit-exact with the reference's normalised affine output)",
+            "value": n * world * args.steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32x9 (29-bit digits, v_mad_i64_i32)",
+            "data": "synthetic (seeded k_i*G0 bases, uniform scalars mod n)",
+            "config": {
+                "workload": f"single BN256 G1 MSM, 2^{args.log2n} points per GPU x {world} GPU(s) "
+                            f"(BASELINE.json configs[2] at log2n=20; configs[4] at log2n=21, 8 GPUs)",
+                "points_per_gpu": n,
+                "fixed_base_table": not args.no_precompute,
+                "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials",
+                "setup_seconds_bases": setup_s,
+                "result_xy": result.hex(),
+            },
+            "phases_ms": {"recode_count": phase[0], "scan": phase[1], "scatter": phase[2], "accumulate": phase[3],
+                          "fix": phase[4], "reduce": phase[5], "device_total": phase[6]},
+            "roofline": {
+                "bound": "valu_int",
+                "kernel": "k_accumulate",
+                "achieved": achieved,
+                "peak": IMAD_PEAK,
+                "unit": "IMAD/s",
+                "frac": achieved / IMAD_PEAK,
+                "traffic": None,
+                "whole_msm_frac": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            v, _ = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"] = {
+                "value": v, "unit": "points/s", "cores": 1, "kind": "port",
+                "sample": f"first {args.cpu_sample} terms of the same seeded workload, reference algorithm "
+                          f"(per-term double-and-add + add, go/bp/util.go:165-175) restated in C, 1 thread",
+            }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
