@@ -108,38 +108,9 @@ __device__ __forceinline__ fe fe_norm(const fe& a) {
   return r;
 }
 
-// acc += x * y  (signed 32x32+64 -> 64; one VOP3 instruction, no carry handling)
-#define FE_MAD(acc, x, y) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc")
-#define FE_MADC(acc, x, yc) asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(yc) : "vcc")
-
-// Montgomery product a*b/R mod p, finely integrated product scanning, radix 2^29.
-__device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) {
-  i64 acc = 0;
-  i32 m[9];
-  fe r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-#pragma unroll
-    for (int i = 0; i <= k; i++) FE_MAD(acc, a.v[i], b.v[k - i]);
-#pragma unroll
-    for (int i = 0; i < k; i++) FE_MADC(acc, m[i], fe_p_limb(k - i));
-    m[k] = (i32)(((u32)acc * (u32)FE_NP) & FE_MASK);
-    FE_MADC(acc, m[k], fe_p_limb(0));
-    acc >>= 29;
-  }
-#pragma unroll
-  for (int k = 9; k < 17; k++) {
-#pragma unroll
-    for (int i = k - 8; i < 9; i++) {
-      FE_MAD(acc, a.v[i], b.v[k - i]);
-      FE_MADC(acc, m[i], fe_p_limb(k - i));
-    }
-    r.v[k - 9] = (i32)acc & FE_MASK;
-    acc >>= 29;
-  }
-  r.v[8] = (i32)acc;
-  return r;
-}
+// Montgomery product a*b/R mod p, finely integrated product scanning, radix 2^29:
+// 162 v_mad_i64_i32 (signed 32x32+64 -> 64, no carry handling) + 9 v_mul_lo_u32.
+#include "fe_mul_gen.inc"
 
 // Portable restatement of fe_mul (no inline asm) used by the on-device self test.
 __device__ __forceinline__ fe fe_mul_portable(const fe& a, const fe& b) {
@@ -202,7 +173,7 @@ __device__ __forceinline__ void fe_canon_step(fe& t) {
 
 // Full reduction to the canonical representative in [0, p), normalised limbs.
 // Requires |value| < 16 p.
-__device__ __noinline__ fe fe_canon(const fe& a) {
+__device__ __noinline__ fe fe_canon(fe a) {  // by value: arguments travel in VGPRs, no scratch
   constexpr fe_kp p16 = fe_make_kp(4);
   fe t;
 #pragma unroll
@@ -264,7 +235,7 @@ __device__ __forceinline__ fe fe_from_mont(const fe& a) {
 }
 
 // a^(p-2).  Exponent is a compile-time constant: the multiply branch is wave-uniform.
-__device__ __noinline__ fe fe_inv(const fe& a_in) {
+__device__ __noinline__ fe fe_inv(fe a_in) {
   const u32 e[8] = {0x5e089667u - 2u, 0x185cac6cu, 0x20b5b59eu, 0xee5b88d1u,
                     0x6184dc21u, 0xaa6fecb8u, 0x4aa387f9u, 0x8fb501e3u};
   fe a = fe_norm(a_in);

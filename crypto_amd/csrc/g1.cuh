@@ -111,7 +111,7 @@ __device__ __forceinline__ void aff_store_inf(aff_mem* p) {
 }
 
 // 2 * (x, y) for an affine point (mdbl-2008-s-1).  BN256 G1 has prime order, so y != 0.
-__device__ __noinline__ void xyzz_dbl_affine(xyzz& r, const fe& x, const fe& y_in) {
+__device__ __forceinline__ void xyzz_dbl_affine(xyzz& r, const fe& x, const fe& y_in) {
   fe y = fe_norm(y_in);
   fe yy = fe_sqr(y);
   fe v = fe_norm(fe_small_mul(yy, 4));
@@ -128,7 +128,7 @@ __device__ __noinline__ void xyzz_dbl_affine(xyzz& r, const fe& x, const fe& y_i
 }
 
 // r = 2a (dbl-2008-s-1)
-__device__ __noinline__ void xyzz_dbl(xyzz& r, const xyzz& a) {
+__device__ __forceinline__ void xyzz_dbl(xyzz& r, const xyzz& a) {
   if (xyzz_is_inf(a)) {
     xyzz_set_inf(r);
     return;
@@ -149,13 +149,23 @@ __device__ __noinline__ void xyzz_dbl(xyzz& r, const xyzz& a) {
   r.zzz = zzz3;
 }
 
-// Rare path of the mixed addition: U2 == X1.  Kept out of line so the hot loop stays small.
-__device__ __noinline__ void xyzz_madd_special(xyzz& acc, const fe& x2, const fe& y2, const fe& rr) {
+// Rare paths (operands equal or opposite).  Out of line and BY VALUE: arguments and results
+// travel in VGPRs / the callee's frame, so the callers' accumulators never need an address
+// (an accumulator passed by reference to a noinline function is demoted to scratch memory
+// for the whole kernel).
+__device__ __noinline__ xyzz xyzz_madd_special(fe x2, fe y2, fe rr) {
+  xyzz r;
   if (fe_is_zero_mod_p(rr)) {
-    xyzz_dbl_affine(acc, x2, y2);  // P == Q
+    xyzz_dbl_affine(r, x2, y2);  // P == Q
   } else {
-    xyzz_set_inf(acc);  // P == -Q
+    xyzz_set_inf(r);  // P == -Q
   }
+  return r;
+}
+__device__ __noinline__ xyzz xyzz_dbl_outofline(xyzz a) {
+  xyzz r;
+  xyzz_dbl(r, a);
+  return r;
 }
 
 // acc += (x2, y2), affine operand not at infinity (madd-2008-s): 8M + 2S.
@@ -171,7 +181,7 @@ __device__ __forceinline__ void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2)
   fe pp = fe_sqr(h);
   if (__builtin_expect(fe_maybe_zero_sq(pp), 0)) {
     if (fe_is_zero_mod_p(h)) {
-      xyzz_madd_special(acc, x2, y2, rr);
+      acc = xyzz_madd_special(x2, y2, rr);
       return;
     }
   }
@@ -186,7 +196,7 @@ __device__ __forceinline__ void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2)
 }
 
 // r = a + b, both XYZZ (add-2008-s): 12M + 2S, all special cases.
-__device__ __noinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) {
+__device__ __forceinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) {
   if (xyzz_is_inf(a)) {
     r = b;
     return;
@@ -205,7 +215,7 @@ __device__ __noinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) {
   if (fe_maybe_zero_sq(pp)) {
     if (fe_is_zero_mod_p(h)) {
       if (fe_is_zero_mod_p(rr)) {
-        xyzz_dbl(r, a);
+        r = xyzz_dbl_outofline(a);
       } else {
         xyzz_set_inf(r);
       }
@@ -225,7 +235,7 @@ __device__ __noinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) {
 }
 
 // Normalise to affine; outputs canonical Montgomery limbs.  Returns false for infinity.
-__device__ __noinline__ bool xyzz_to_affine(fe& x, fe& y, const xyzz& a) {
+__device__ __forceinline__ bool xyzz_to_affine(fe& x, fe& y, const xyzz& a) {
   if (xyzz_is_inf(a)) return false;
   fe zi3 = fe_inv(a.zzz);          // 1 / Z^3
   fe zi = fe_mul(a.zz, zi3);       // 1 / Z

@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_precompute_level(const aff_mem* __restr
 
 // ------------------------------------------------------------------ element-wise point ops
 // acc = k * (x, y), MSB-first double-and-add on the signed representative of k.
-__device__ __noinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& y_in, u32 k[8]) {
+__device__ __forceinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& y_in, u32 k[8]) {
   bool neg = scalar_reduce_signed(k);
   fe y = neg ? fe_neg(y_in) : y_in;
   xyzz_set_inf(acc);
