@@ -44,6 +44,7 @@ struct bn256_ctx {
   hipEvent_t ev[8];
   float last_ms[7];
   int tune_c, tune_k;
+  int lds_attr_set;
   u32* h_pack;      // pinned
   size_t h_pack_cap;
   u32* d_err;
@@ -276,8 +277,25 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   const size_t npack = (size_t)nsets * (q + 1);
 
   int rc;
-  if ((rc = ws_reserve(ctx, WS_RANK, entries * 4))) return rc;
-  if ((rc = ws_reserve(ctx, WS_SKEY, entries * 4))) return rc;
+  // LDS-staged sort when one set's histogram fits the 160 KB LDS (nb <= 2^15)
+  const bool use_lds = (size_t)nb * 4 <= 128 * 1024;
+  const size_t lds_bytes = (size_t)nb * 4;
+  u32 ntiles = 1, tile_len = (u32)n;
+  if (use_lds) {
+    u32 want = std::max<u32>(1, 256 / nsets);
+    ntiles = (u32)std::min<size_t>(want, (n + 1023) / 1024);
+    if (ntiles < 1) ntiles = 1;
+    tile_len = (u32)((n + ntiles - 1) / ntiles);
+    ntiles = (u32)((n + tile_len - 1) / tile_len);
+    if ((rc = ws_reserve(ctx, WS_RANK, (size_t)nsets * ntiles * nb * 4))) return rc;  // per-tile histograms
+    if (lds_bytes > 48 * 1024 && !ctx->lds_attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      ctx->lds_attr_set = 1;
+    }
+  } else {
+    if ((rc = ws_reserve(ctx, WS_RANK, entries * 4))) return rc;
+  }
   if ((rc = ws_reserve(ctx, WS_SVAL, entries * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_COUNTS, (nbt + 1) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
@@ -290,7 +308,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   u32* counts = (u32*)ctx->ws[WS_COUNTS];
   u32* offsets = (u32*)ctx->ws[WS_OFFSETS];
   u32* rank = (u32*)ctx->ws[WS_RANK];
-  u32* skey = (u32*)ctx->ws[WS_SKEY];
+  u32* hist = rank;
   u32* sval = (u32*)ctx->ws[WS_SVAL];
   u32* blocksum = (u32*)ctx->ws[WS_BLOCKSUM];
   xyzz_mem* buckets = (xyzz_mem*)ctx->ws[WS_BUCKETS];
@@ -299,21 +317,33 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   hipStream_t s = ctx->stream;
 
   HIPCHK(hipEventRecord(ctx->ev[0], s));
-  HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
-  hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                     (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)nullptr, (u32*)nullptr,
-                     (u32*)nullptr);
-  HIPCHK(hipEventRecord(ctx->ev[1], s));
+  if (use_lds) {
+    hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
+                       (u32)W, nb, (u32)precomp, (u32)off, (u32)b->n, tile_len, hist, (const u32*)nullptr,
+                       (u32*)nullptr);
+    HIPCHK(hipEventRecord(ctx->ev[1], s));
+    hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
+  } else {
+    HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
+    hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
+                       (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)nullptr, (u32*)nullptr);
+    HIPCHK(hipEventRecord(ctx->ev[1], s));
+  }
   // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
   hipLaunchKernelGGL(k_scan1, dim3(nscan), dim3(SCAN_BLOCK), 0, s, (const u32*)counts, offsets, (u32)(nbt + 1), blocksum);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, blocksum, nscan, blocksum + nscan);
   hipLaunchKernelGGL(k_scan3, dim3(nscan), dim3(SCAN_BLOCK), 0, s, offsets, (u32)(nbt + 1), (const u32*)blocksum);
   HIPCHK(hipEventRecord(ctx->ev[2], s));
-  hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                     (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)offsets, skey, sval);
+  if (use_lds) {
+    hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
+                       (u32)W, nb, (u32)precomp, (u32)off, (u32)b->n, tile_len, hist, (const u32*)offsets, sval);
+  } else {
+    hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
+                       (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)offsets, sval);
+  }
   HIPCHK(hipEventRecord(ctx->ev[3], s));
-  hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)skey,
-                     (const u32*)sval, (const u32*)(offsets + nbt), K, buckets, partials);
+  hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
+                     (const u32*)offsets, (u32)nbt, K, buckets, partials);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
   hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
                      (const xyzz_mem*)partials);

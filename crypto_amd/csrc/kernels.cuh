@@ -1,9 +1,9 @@
 // HIP kernels of the BN256 G1 MSM engine (gfx950).  Pipeline of one MSM
 // (vectorPointScalarMul, go/bp/util.go:165-175, go/bppp/util.go:178-196):
 //
-//   k_recode<false>   signed c-bit digits of every scalar + per-bucket counts (rank by atomic)
-//   k_scan1/2/3       exclusive scan of the bucket counts -> bucket offsets
-//   k_recode<true>    scatter of (bucket key, base index|sign) into bucket order (counting sort)
+//   k_tile_sort<0>    signed c-bit digits of every scalar, per-tile LDS bucket histograms
+//   k_tile_scan       per-bucket prefix over tiles;  k_scan1/2/3: bucket totals -> bucket offsets
+//   k_tile_sort<1>    LDS cursors, scatter of (base index|sign) into bucket order (counting sort)
 //   k_accumulate      balanced segmented bucket accumulation, XYZZ mixed additions
 //   k_bucket_fix      joins the partial sums of buckets that straddle thread chunks
 //   k_fold            log-depth bucket reduction: T = sum B_b and G_k = sum_{bit k of b} B_b
@@ -92,39 +92,126 @@ __device__ __forceinline__ u32 scalar_bits(const u32 k[8], u32 bit, u32 width) {
 }
 
 // ------------------------------------------------------------------ recode / count / scatter
-// One thread per scalar.  Signed digits d_w in [-2^(c-1), 2^(c-1)], sum d_w 2^(cw) = +-k.
-// Bucket key = (window set) * nb + |d| - 1; entry value = (table index << 1) | sign.
-//   SCATTER = false: rank[w*n+i] = atomicAdd(count[key], 1)
-//   SCATTER = true : skey/sval[offsets[key] + rank] = key / value
+// Signed digits d_w in [-2^(c-1), 2^(c-1)], sum d_w 2^(cw) = +-k.  Bucket key within a set =
+// |d| - 1; entry value = (table index << 1) | sign.  A "set" is a group of windows sharing one
+// bucket array: all W windows with a fixed-base table (precomp), one window per set without.
+//
+// The sort is a counting sort staged through LDS (160 KB per CU holds a whole 2^15-bucket
+// histogram): workgroup (tile, set) owns a contiguous tile of scalars.
+//   k_tile_count   : LDS histogram of the tile's digits -> hist[set][tile][bucket]
+//   k_tile_scan    : per (set, bucket) exclusive prefix over tiles, totals[set*nb + bucket]
+//   k_scan1/2/3    : exclusive scan of totals -> offsets[bucket]  (offsets[nbt] = #entries)
+//   k_tile_scatter : LDS cursors = offsets + tile prefix; pos = ds_add_rtn(cursor[key], 1);
+//                    sval[pos] = entry.  No global atomics anywhere.
+#define RECODE_MAXW 64
+struct recoded {
+  u32 k[8];
+  bool neg;
+};
+// digit of window w (call with w = 0, 1, 2, ... in order; carry threads through)
+__device__ __forceinline__ void recode_digit(const u32 k[8], bool neg, u32 w, u32 c, u32& carry, u32& mag, u32& sign) {
+  const u32 half = 1u << (c - 1);
+  u32 raw = scalar_bits(k, w * c, c) + carry;
+  bool over = raw > half;
+  mag = over ? ((1u << c) - raw) : raw;
+  carry = over ? 1u : 0u;
+  sign = (over != neg) ? 1u : 0u;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 nb,
+                                                    u32 precomp, u32 base_off, u32 level_stride, u32 tile_len,
+                                                    u32* __restrict__ hist, const u32* __restrict__ offsets,
+                                                    u32* __restrict__ sval) {
+  extern __shared__ u32 lds[];
+  const u32 tile = blockIdx.x, set = blockIdx.y, ntiles = gridDim.x;
+  u32* h = hist + ((size_t)set * ntiles + tile) * nb;
+  if (!SCATTER) {
+    for (u32 j = threadIdx.x; j < nb; j += blockDim.x) lds[j] = 0;
+  } else {
+    const u32* o = offsets + (size_t)set * nb;
+    for (u32 j = threadIdx.x; j < nb; j += blockDim.x) lds[j] = o[j] + h[j];
+  }
+  __syncthreads();
+  u32 lo = tile * tile_len;
+  u32 hi = (n - lo > tile_len) ? lo + tile_len : n;
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 k[8];
+    scalar_load_be(k, scalars_be + (size_t)i * 32);
+    bool neg = scalar_reduce_signed(k);
+    u32 carry = 0;
+    for (u32 w = 0; w < W; w++) {
+      u32 mag, sign;
+      recode_digit(k, neg, w, c, carry, mag, sign);
+      if (mag == 0 || (!precomp && w != set)) continue;
+      if (!SCATTER) {
+        atomicAdd(&lds[mag - 1], 1u);
+      } else {
+        u32 pos = atomicAdd(&lds[mag - 1], 1u);
+        u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i;
+        sval[pos] = (tidx << 1) | sign;
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < nb; j += blockDim.x) h[j] = lds[j];
+  }
+}
+
+// thread per (set, bucket): exclusive prefix of hist over tiles (in place) and the bucket total
+__global__ void __launch_bounds__(256) k_tile_scan(u32* __restrict__ hist, u32 nsets, u32 ntiles, u32 nb,
+                                                   u32* __restrict__ totals) {
+  u32 id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= nsets * nb) {
+    if (id == nsets * nb) totals[id] = 0;  // sentinel so that the scan yields offsets[nbt] = total
+    return;
+  }
+  u32 set = id / nb, b = id % nb;
+  u32* h = hist + (size_t)set * ntiles * nb + b;
+  u32 run = 0;
+  u32 t = 0;
+  for (; t + 8 <= ntiles; t += 8) {
+    u32 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = h[(size_t)(t + j) * nb];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      h[(size_t)(t + j) * nb] = run;
+      run += v[j];
+    }
+  }
+  for (; t < ntiles; t++) {
+    u32 v = h[(size_t)t * nb];
+    h[(size_t)t * nb] = run;
+    run += v;
+  }
+  totals[id] = run;
+}
+
+// Fallback for bucket arrays too large for LDS (nb * 4 > 128 KB): global-atomic counting sort.
+//   SCATTER = false: rank[w*n+i] = atomicAdd(count[key], 1);  SCATTER = true: sval[offsets[key] + rank] = entry
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W,
                                                 u32 nb, u32 precomp, u32 base_off, u32 level_stride,
                                                 u32* __restrict__ counts, u32* __restrict__ rank,
-                                                const u32* __restrict__ offsets, u32* __restrict__ skey,
-                                                u32* __restrict__ sval) {
+                                                const u32* __restrict__ offsets, u32* __restrict__ sval) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 k[8];
   scalar_load_be(k, scalars_be + (size_t)i * 32);
   bool neg = scalar_reduce_signed(k);
   u32 carry = 0;
-  const u32 half = 1u << (c - 1);
   for (u32 w = 0; w < W; w++) {
-    u32 bit = w * c;
-    u32 width = (bit + c <= 256) ? c : (256 - bit);
-    u32 raw = scalar_bits(k, bit, width) + carry;
-    bool over = raw > half;
-    u32 mag = over ? ((1u << c) - raw) : raw;
-    carry = over ? 1u : 0u;
+    u32 mag, sign;
+    recode_digit(k, neg, w, c, carry, mag, sign);
     if (mag == 0) continue;
-    u32 sign = (over != neg) ? 1u : 0u;
     u32 key = (precomp ? 0u : w * nb) + mag - 1u;
     if (!SCATTER) {
       rank[(size_t)w * n + i] = atomicAdd(&counts[key], 1u);
     } else {
       u32 pos = offsets[key] + rank[(size_t)w * n + i];
       u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i;
-      skey[pos] = key;
       sval[pos] = (tidx << 1) | sign;
     }
   }
@@ -200,41 +287,47 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32
 }
 
 // ------------------------------------------------------------------ bucket accumulation
-// Thread t owns the sorted entries [t*K, (t+1)*K).  Runs of equal key are summed with mixed
-// additions.  A run that neither continues from thread t-1 nor into thread t+1 is a complete
-// bucket; otherwise it is a partial: slot 2t if it continues from the previous thread
-// (possibly also into the next), slot 2t+1 if it only continues into the next.
-__global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ table, const u32* __restrict__ skey,
-                                                    const u32* __restrict__ sval, const u32* __restrict__ total_ptr,
-                                                    u32 K, xyzz_mem* __restrict__ buckets,
+// Thread t owns the sorted entries [t*K, (t+1)*K); bucket boundaries come from offsets[].
+// Runs of one bucket are summed with mixed additions.  A run that neither continues from
+// thread t-1 nor into thread t+1 is a complete bucket; otherwise it is a partial: slot 2t if
+// it continues from the previous thread (possibly also into the next), slot 2t+1 if it only
+// continues into the next.
+__global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ table, const u32* __restrict__ sval,
+                                                    const u32* __restrict__ offsets, u32 nbt, u32 K,
+                                                    xyzz_mem* __restrict__ buckets,
                                                     xyzz_mem* __restrict__ partials) {
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 M = *total_ptr;
+  u32 M = offsets[nbt];
   u64 start64 = (u64)t * K;
   if (start64 >= M) return;
   u32 start = (u32)start64;
   u32 end = (M - start > K) ? start + K : M;
-  u32 prev_key = start > 0 ? skey[start - 1] : NOKEY;
-  u32 next_key = end < M ? skey[end] : NOKEY;
-  u32 cur = skey[start];
-  bool first = true;
+  // cur = the bucket containing entry `start`: first b with offsets[b+1] > start
+  u32 lo = 0, hi = nbt - 1;
+  while (lo < hi) {
+    u32 mid = (lo + hi) >> 1;
+    if (offsets[mid + 1] <= start) lo = mid + 1; else hi = mid;
+  }
+  u32 cur = lo;
+  u32 bend = offsets[cur + 1];
+  bool head = offsets[cur] < start;  // first run continues from the previous thread
   xyzz acc;
   xyzz_set_inf(acc);
   for (u32 e = start; e < end; e++) {
-    u32 key = skey[e];
     u32 val = sval[e];
-    if (key != cur) {
-      bool head = first && (cur == prev_key);
+    if (e >= bend) {
       xyzz_store(head ? &partials[2 * (size_t)t] : &buckets[cur], acc);
-      first = false;
-      cur = key;
+      head = false;
+      do {
+        cur++;
+        bend = offsets[cur + 1];
+      } while (e >= bend);
       xyzz_set_inf(acc);
     }
     fe x2, y2;
     if (aff_load(x2, y2, &table[val >> 1], (val & 1u) != 0)) xyzz_madd(acc, x2, y2);
   }
-  bool head = first && (cur == prev_key);
-  bool tail = (cur == next_key);
+  bool tail = bend > end;
   xyzz_mem* dst = head ? &partials[2 * (size_t)t] : (tail ? &partials[2 * (size_t)t + 1] : &buckets[cur]);
   xyzz_store(dst, acc);
 }
