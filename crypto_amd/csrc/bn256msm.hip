@@ -297,6 +297,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
     if ((rc = ws_reserve(ctx, WS_RANK, entries * 4))) return rc;
   }
   if ((rc = ws_reserve(ctx, WS_SVAL, entries * 4))) return rc;
+  if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
   if ((rc = ws_reserve(ctx, WS_COUNTS, (nbt + 1) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BLOCKSUM, (size_t)(nscan + 1) * 4))) return rc;
@@ -314,9 +315,12 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   xyzz_mem* buckets = (xyzz_mem*)ctx->ws[WS_BUCKETS];
   xyzz_mem* partials = (xyzz_mem*)ctx->ws[WS_PARTIALS];
   u32* d_pack = (u32*)ctx->ws[WS_PACK];
+  u32* heavy_count = ctx->d_err + 16;
+  u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
 
   HIPCHK(hipEventRecord(ctx->ev[0], s));
+  HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
   if (use_lds) {
     hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
                        (u32)W, nb, (u32)precomp, (u32)off, (u32)b->n, tile_len, hist, (const u32*)nullptr,
@@ -346,7 +350,9 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
                      (const u32*)offsets, (u32)nbt, K, buckets, partials);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
   hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
-                     (const xyzz_mem*)partials);
+                     (const xyzz_mem*)partials, heavy_count, heavy_list);
+  hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
+                     (const u32*)heavy_count, (const u32*)heavy_list);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);

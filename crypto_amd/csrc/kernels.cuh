@@ -333,10 +333,14 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
 }
 
 // One thread per bucket: empty buckets become infinity; buckets that straddle chunks
-// t0 < t1 are the sum of partials 2*t0+1, 2*t (t0 < t < t1), 2*t1.
+// t0 < t1 are the sum of partials 2*t0+1, 2*t (t0 < t < t1), 2*t1.  Buckets with more than
+// FIX_CAP partials (heavy buckets: skewed scalar distributions such as the Bulletproofs
+// 0/1 bit vectors, go/bp/main.go:84-85, or a narrow top window) are queued for k_heavy.
+#define FIX_CAP 32
 __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offsets, u32 nbt, u32 K,
                                                    xyzz_mem* __restrict__ buckets,
-                                                   const xyzz_mem* __restrict__ partials) {
+                                                   const xyzz_mem* __restrict__ partials,
+                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbt) return;
   u32 lo = offsets[b], hi = offsets[b + 1];
@@ -348,6 +352,10 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
   }
   u32 t0 = lo / K, t1 = (hi - 1) / K;
   if (t0 == t1) return;
+  if (t1 - t0 + 1 > FIX_CAP) {
+    heavy_list[atomicAdd(heavy_count, 1u)] = b;
+    return;
+  }
   xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
   for (u32 t = t0 + 1; t <= t1; t++) {
     xyzz p, r;
@@ -356,6 +364,44 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
     acc = r;
   }
   xyzz_store(&buckets[b], acc);
+}
+
+// One workgroup per heavy bucket: the threads split the partials (strided), then a
+// log-depth tree through LDS.
+__global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, u32 K, xyzz_mem* __restrict__ buckets,
+                                               const xyzz_mem* __restrict__ partials,
+                                               const u32* __restrict__ heavy_count,
+                                               const u32* __restrict__ heavy_list) {
+  __shared__ xyzz_mem sh[256];
+  const u32 nheavy = *heavy_count;
+  for (u32 j = blockIdx.x; j < nheavy; j += gridDim.x) {
+    u32 b = heavy_list[j];
+    u32 t0 = offsets[b] / K, t1 = (offsets[b + 1] - 1) / K;
+    u32 np = t1 - t0 + 1;
+    xyzz acc;
+    xyzz_set_inf(acc);
+    for (u32 i = threadIdx.x; i < np; i += blockDim.x) {
+      size_t slot = i == 0 ? 2 * (size_t)t0 + 1 : 2 * ((size_t)t0 + i);
+      xyzz p, r;
+      xyzz_load(p, &partials[slot]);
+      xyzz_add(r, acc, p);
+      acc = r;
+    }
+    xyzz_store(&sh[threadIdx.x], acc);
+    __syncthreads();
+    for (u32 s = 128; s >= 1; s >>= 1) {
+      if (threadIdx.x < s) {
+        xyzz p, r;
+        xyzz_load(p, &sh[threadIdx.x + s]);
+        xyzz_add(r, acc, p);
+        acc = r;
+        xyzz_store(&sh[threadIdx.x], acc);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) xyzz_store(&buckets[b], acc);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------ bucket reduction

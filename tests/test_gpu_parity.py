@@ -205,3 +205,21 @@ def test_scalar_mul_batch_1024_vs_oracle(eng, orc):
     sc = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(n)]
     assert b"".join(eng.scalar_mul_each(h, sc).download()) == orc.scalar_mul_each(braw, sraw)
     assert b"".join(eng.vector_point_mul_on_scalar(h, sc[0]).download()) == orc.scalar_mul_each(braw, sraw[:32], broadcast=True)
+
+
+@pytest.mark.parametrize("mode", ["plain", "precomp"])
+def test_skewed_scalar_distributions_65536(eng, orc, mode):
+    """Bulletproofs-like scalars (go/bp/main.go:84-85: al in {0,1}, ar in {0,n-1}) and an
+    all-equal vector put most terms into one or two buckets; result must still be bit-exact."""
+    import crypto_amd
+    n = 1 << 16
+    braw = orc.synth_bases(0xBB01, n)
+    h = eng.upload(braw, crypto_amd.PRECOMPUTE if mode == "precomp" else 0)
+    half = n // 2
+    sc = [(i * 2654435761 >> 7) & 1 for i in range(half)] + [(N_ORDER - 1) if (i * 40503 >> 5) & 1 else 0 for i in range(half)]
+    sraw = b"".join(s.to_bytes(32, "big") for s in sc)
+    assert eng.msm(h, sraw) == orc.msm(braw, sraw, mt=True)
+    sraw = (5).to_bytes(32, "big") * n
+    assert eng.msm(h, sraw) == orc.msm(braw, sraw, mt=True)
+    sraw = ((1 << 240) + 3).to_bytes(32, "big") * n
+    assert eng.msm(h, sraw) == orc.msm(braw, sraw, mt=True)
