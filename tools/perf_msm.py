@@ -18,6 +18,8 @@ args = ap.parse_args()
 
 eng = crypto_amd.Engine(0)
 n = 1 << args.log2n
+if os.environ.get("PERF_PREALLOC"):
+    dummy = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
 scal = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
 eng.random_scalars_into(0x5EED0002, n, scal.data_ptr())
 names = ["recode", "scan", "scatter", "accum", "fix", "reduce", "total"]
@@ -30,6 +32,8 @@ for cfg in args.configs.split(","):
     for _ in range(args.reps):
         r = eng.msm_dev(bases, scal.data_ptr(), n)
         t = eng.last_timing()
+        if os.environ.get("PERF_ALL"):
+            print("   rep", " ".join(f"{v:7.3f}" for v in t), flush=True)
         if best is None or t[6] < best[6]:
             best = t
     if ref is None:

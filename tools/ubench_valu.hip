@@ -39,6 +39,21 @@ __global__ void __launch_bounds__(256) kern(u32* out, int iters, u32 seed) {
         if (KIND == 9) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");  // dependent chain
         if (KIND == 10) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(t32[i]) : "v"(a), "v"(b));
         if (KIND == 11) asm volatile("v_mov_b32 %0, %1" : "+v"(t32[i]) : "v"(t32[(i + 1) % NACC]));
+        if (KIND == 12) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+        if (KIND == 13) asm volatile("v_ashrrev_i64 %0, 29, %0" : "+v"(acc[i]));
+        if (KIND == 14) asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(t32[i]) : "v"(a));
+        if (KIND == 15) asm volatile("v_and_b32 %0, %1, %0" : "+v"(t32[i]) : "v"(a));
+        if (KIND == 16) asm volatile("v_ashrrev_i32 %0, 29, %0" : "+v"(t32[i]));
+        if (KIND == 17) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(t32[i]) : "v"(a));
+        if (KIND == 18) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\ts_nop 0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+        if (KIND == 19) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "s"(seed) : "vcc");
+        if (KIND == 20) asm volatile("v_bfe_u32 %0, %0, 0, 29" : "+v"(t32[i]));
+        if (KIND == 21) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(t32[i]));
+        if (KIND == 22) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(t32[i]) : "v"(a) : "vcc");
+        if (KIND == 23) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(t32[i]) : "v"(a));
+        if (KIND == 24) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_and_b32 %3, %4, %3" : "+v"(acc[i]), "+v"(t32[i]) : "v"(a), "v"(b), "v"(a) : "vcc");
+        if (KIND == 25) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(t32[i]) : "v"(a));
+        if (KIND == 26) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(t32[i]) : "v"(a), "v"(b));
       }
     }
   }
@@ -78,7 +93,7 @@ int main() {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   int ncu = p.multiProcessorCount;
   printf("device %s  CUs=%d  clock=%d kHz\n", p.name, ncu, p.clockRate);
-  for (int w : {1, 2, 4}) {
+  for (int w : {4}) {
     run<0>("v_mad_u64_u32", w, ncu, 1);
     run<9>("v_mad_u64_u32 (dep chain)", w, ncu, 1);
     run<6>("v_mad_u64_u32+v_addc", w, ncu, 1);
@@ -91,6 +106,21 @@ int main() {
     run<11>("v_mov_b32", w, ncu, 1);
     run<5>("v_lshl_add_u64", w, ncu, 1);
     run<4>("v_fma_f64", w, ncu, 1);
+    run<12>("v_mad_i64_i32", w, ncu, 1);
+    run<19>("v_mad_i64_i32 (sgpr src)", w, ncu, 1);
+    run<18>("v_mad_i64_i32 + s_nop 0", w, ncu, 1);
+    run<24>("v_mad_i64_i32 + v_and", w, ncu, 1);
+    run<13>("v_ashrrev_i64", w, ncu, 1);
+    run<14>("v_alignbit_b32", w, ncu, 1);
+    run<15>("v_and_b32", w, ncu, 1);
+    run<16>("v_ashrrev_i32", w, ncu, 1);
+    run<17>("v_sub_u32", w, ncu, 1);
+    run<20>("v_bfe_u32", w, ncu, 1);
+    run<21>("v_lshlrev_b32", w, ncu, 1);
+    run<22>("v_cndmask_b32", w, ncu, 1);
+    run<23>("v_mul_i32_i24", w, ncu, 1);
+    run<25>("v_pk_mul_lo_u16", w, ncu, 1);
+    run<26>("v_dot4_i32_i8", w, ncu, 1);
   }
   return 0;
 }
