@@ -71,6 +71,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import crypto_amd
+    from crypto_amd import sharding
     eng = crypto_amd.Engine(local_rank)
     eng.set_tuning(args.window_bits, args.chunk)
     n = 1 << args.log2n
@@ -81,17 +82,12 @@ def main():
     setup_s = time.perf_counter() - t0
     scalars = torch.empty(n * 32, dtype=torch.uint8, device=dev)
     eng.random_scalars_into(SEED_SCALARS, n, scalars.data_ptr(), first=first)
-    part = torch.zeros(64, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(64 * world, dtype=torch.uint8, device=dev)
 
     def step():
         p = eng.msm_dev(bases, scalars.data_ptr(), n)
         if world == 1:
             return p
-        part.copy_(torch.frombuffer(bytearray(p), dtype=torch.uint8))
-        dist.all_gather_into_tensor(gathered, part)
-        raw = bytes(gathered.cpu().numpy().tobytes())
-        return eng.g1_sum([raw[64 * i:64 * i + 64] for i in range(world)])
+        return sharding.combine(sharding.all_gather_points(p, dev))
 
     def sync():
         if world > 1:
