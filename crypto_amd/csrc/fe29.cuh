@@ -109,7 +109,8 @@ __device__ __forceinline__ fe fe_norm(const fe& a) {
 }
 
 // Montgomery product a*b/R mod p, finely integrated product scanning, radix 2^29:
-// 162 v_mad_i64_i32 (signed 32x32+64 -> 64, no carry handling) + 9 v_mul_lo_u32.
+// 162 v_mad_i64_i32 (signed 32x32+64 -> 64, no carry handling) + 9 v_mul_lo_u32; the square
+// uses pre-doubled cross terms (126 + 9).
 #include "fe_mul_gen.inc"
 
 // Portable restatement of fe_mul (no inline asm) used by the on-device self test.
@@ -141,7 +142,6 @@ __device__ __forceinline__ fe fe_mul_portable(const fe& a, const fe& b) {
   return r;
 }
 
-__device__ __forceinline__ fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 
 // normalised limbs of p * 2^S (compile-time)
 struct fe_kp {
