@@ -271,7 +271,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   if (entries >= (1ull << 31) || (unsigned long long)b->n * b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
   const u32 q = (u32)(c - 1);
 
-  u32 K = ctx->tune_k ? (u32)ctx->tune_k : (u32)std::min<unsigned long long>(128, std::max<unsigned long long>(16, entries / 262144));
+  u32 K = ctx->tune_k ? (u32)ctx->tune_k : (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(16, entries / 262144));
   const size_t T = (size_t)((entries + K - 1) / K);
   const u32 nscan = nblocks(nbt + 1, SCAN_TILE);
   const size_t npack = (size_t)nsets * (q + 1);
