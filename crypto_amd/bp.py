@@ -1,0 +1,84 @@
+"""ctypes binding of libbpamd.so (include/bp_amd.h): the C++ host-side mirror of go/bp."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbpamd.so")
+EXPORTS = ["bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error"]
+_bp = None
+
+
+def load() -> C.CDLL:
+    global _bp
+    if _bp is not None:
+        return _bp
+    _lib.load()  # libbn256msm first (and torch's HIP runtime before it)
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m crypto_amd.build`")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.bp_prove_det.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, sz, C.POINTER(sz)]
+    lib.bp_verify_det.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, sz]
+    lib.bp_inner_product_roundtrip.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int]
+    lib.bp_keccak256.argtypes = [C.c_char_p, sz, C.c_char_p]
+    lib.bp_last_error.restype = C.c_char_p
+    _bp = lib
+    return lib
+
+
+class BulletProofs:
+    """NewBulletProofPublic / Prove / Verify (go/bp/main.go) with an injected, seeded reader."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.lib = load()
+
+    def prove(self, n: int, v: int, seed: int) -> bytes:
+        cap = 64 * 5 + 32 * 5 + 4 + 128 * 64
+        out = C.create_string_buffer(cap)
+        ln = C.c_size_t(0)
+        rc = self.lib.bp_prove_det(self.eng.ctx, n, int(v).to_bytes(32, "big"), seed, out, cap, C.byref(ln))
+        if rc:
+            raise RuntimeError(f"bp_prove_det rc={rc}: {self.lib.bp_last_error().decode()}")
+        return out.raw[:ln.value]
+
+    def verify(self, n: int, seed: int, proof: bytes) -> str | None:
+        """None when accepted, else the reference's error string."""
+        rc = self.lib.bp_verify_det(self.eng.ctx, n, seed, proof, len(proof))
+        if rc == 0:
+            return None
+        return self.lib.bp_last_error().decode()
+
+    def inner_product_roundtrip(self, n: int, seed: int, a, b, tamper: bool = False) -> str | None:
+        rc = self.lib.bp_inner_product_roundtrip(
+            self.eng.ctx, n, seed, b"".join(int(x).to_bytes(32, "big") for x in a),
+            b"".join(int(x).to_bytes(32, "big") for x in b), int(tamper))
+        if rc == 0:
+            return None
+        return self.lib.bp_last_error().decode()
+
+
+def parse_proof(raw: bytes) -> dict:
+    """Splits the wire format of include/bp_amd.h into named fields (hex for points, ints for scalars)."""
+    pos = 0
+    out = {}
+    for k in ("V", "A", "S", "T1", "T2"):
+        out[k] = raw[pos:pos + 64].hex()
+        pos += 64
+    for k in ("tx", "taux", "nu"):
+        out[k] = int.from_bytes(raw[pos:pos + 32], "big")
+        pos += 32
+    cnt = int.from_bytes(raw[pos:pos + 4], "big")
+    pos += 4
+    out["L"] = [raw[pos + 64 * i:pos + 64 * i + 64].hex() for i in range(cnt)]
+    pos += 64 * cnt
+    out["R"] = [raw[pos + 64 * i:pos + 64 * i + 64].hex() for i in range(cnt)]
+    pos += 64 * cnt
+    out["a"] = int.from_bytes(raw[pos:pos + 32], "big")
+    out["b"] = int.from_bytes(raw[pos + 32:pos + 64], "big")
+    assert pos + 64 == len(raw)
+    return out

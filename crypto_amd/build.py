@@ -32,5 +32,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+BPLIB = os.path.join(HERE, "libbpamd.so")
+
+
+def build_bp(force: bool = False, verbose: bool = True) -> str:
+    """Host-side go/bp mirror (plain C++, links against libbn256msm.so next to it)."""
+    src = os.path.join(CSRC, "bp_host.cpp")
+    deps = [src, os.path.join(CSRC, "host_g1.h"), os.path.join(HERE, "..", "include", "bp_amd.h"), LIB]
+    if not force and os.path.exists(BPLIB) and all(os.path.getmtime(d) <= os.path.getmtime(BPLIB) for d in deps):
+        return BPLIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", BPLIB, src,
+           "-L" + HERE, "-lbn256msm", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print("[crypto_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return BPLIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_bp(force="--force" in sys.argv)

@@ -1,0 +1,732 @@
+// Host-side mirror of the reference's Bulletproofs package (go/bp) on top of the C ABI of
+// libbn256msm (include/bn256msm.h).  Same names, argument meaning and error behaviour as
+// go/bp/main.go and go/bp/util.go; the Go toolchain is absent from this image, so the host
+// layer is C++ (the reference is compiled code).  Every vector commitment goes through the
+// device library; generators stay device-resident across the inner-product rounds.
+//
+// This is product code; it shares nothing with oracle/.
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bn256msm.h"
+#include "../../include/bp_amd.h"
+#include "host_g1.h"
+
+namespace {
+
+typedef unsigned __int128 u128;
+
+// ------------------------------------------------------------------ Fr = integers mod bn256.Order
+// big.Int + Mod(Order) in the reference (go/bp/util.go:197-207); here 4x64 Montgomery.
+struct Fr {
+  uint64_t l[4];  // Montgomery form
+};
+const uint64_t kN[4] = {0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL, 0xaa6fecb86184dc21ULL, 0x8fb501e34aa387f9ULL};
+const Fr kFrR2 = {{0xb5f030132affbc35ULL, 0x85a1f7da0792e95dULL, 0x26841e5fa6ee4895ULL, 0x3d8f6c73765aefd5ULL}};
+const Fr kFrOne = {{0xe5d10ba4a8538d9fULL, 0xd17271ed07d4c6dbULL, 0x559013479e7b23deULL, 0x704afe1cb55c7806ULL}};
+const uint64_t kFrNInv = 0x056417b72d284e5fULL;
+
+bool geq_n(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; i--)
+    if (a[i] != kN[i]) return a[i] > kN[i];
+  return true;
+}
+void sub_n(uint64_t a[4]) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a[i] - kN[i] - br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+Fr add(const Fr& a, const Fr& b) {
+  Fr r;
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) {
+    c += (u128)a.l[i] + b.l[i];
+    r.l[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  if ((uint64_t)c || geq_n(r.l)) sub_n(r.l);
+  return r;
+}
+Fr sub(const Fr& a, const Fr& b) {  // Go's Mod is Euclidean: the result is always in [0, n)
+  Fr r;
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a.l[i] - b.l[i] - br;
+    r.l[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+  if (br) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)r.l[i] + kN[i];
+      r.l[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  return r;
+}
+Fr mul(const Fr& a, const Fr& b) {
+  uint64_t t[9] = {0};
+  for (int i = 0; i < 4; i++) {
+    uint64_t c = 0;
+    for (int j = 0; j < 4; j++) {
+      u128 cur = (u128)a.l[i] * b.l[j] + t[i + j] + c;
+      t[i + j] = (uint64_t)cur;
+      c = (uint64_t)(cur >> 64);
+    }
+    t[i + 4] = c;
+  }
+  for (int i = 0; i < 4; i++) {
+    uint64_t m = t[i] * kFrNInv;
+    uint64_t c = 0;
+    for (int j = 0; j < 4; j++) {
+      u128 cur = (u128)m * kN[j] + t[i + j] + c;
+      t[i + j] = (uint64_t)cur;
+      c = (uint64_t)(cur >> 64);
+    }
+    for (int k = i + 4; c && k < 9; k++) {
+      u128 cur = (u128)t[k] + c;
+      t[k] = (uint64_t)cur;
+      c = (uint64_t)(cur >> 64);
+    }
+  }
+  Fr r = {{t[4], t[5], t[6], t[7]}};
+  if (t[8] || geq_n(r.l)) sub_n(r.l);
+  return r;
+}
+Fr fr_from_raw(const uint64_t w[4]) {  // any 256-bit value, reduced mod n
+  uint64_t v[4] = {w[0], w[1], w[2], w[3]};
+  if (geq_n(v)) sub_n(v);  // 2^256 < 2n
+  Fr t = {{v[0], v[1], v[2], v[3]}};
+  return mul(t, kFrR2);
+}
+Fr fr_from_u64(uint64_t x) {
+  uint64_t w[4] = {x, 0, 0, 0};
+  return fr_from_raw(w);
+}
+void fr_to_raw(uint64_t w[4], const Fr& a) {
+  Fr one = {{1, 0, 0, 0}};
+  Fr t = mul(a, one);
+  memcpy(w, t.l, 32);
+}
+Fr fr_from_be(const uint8_t b[32]) {
+  uint64_t w[4];
+  hostg1::be_load(w, b);
+  return fr_from_raw(w);
+}
+void fr_to_be(uint8_t b[32], const Fr& a) {  // scalarTo32Byte, go/bp/util.go:209-220
+  uint64_t w[4];
+  fr_to_raw(w, a);
+  hostg1::be_store(b, w);
+}
+Fr fr_inv(const Fr& a) {  // ModInverse(a, Order) via a^(n-2)
+  uint64_t e[4] = {kN[0] - 2, kN[1], kN[2], kN[3]};
+  Fr acc = kFrOne;
+  for (int i = 255; i >= 0; i--) {
+    acc = mul(acc, acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, a);
+  }
+  return acc;
+}
+const Fr kFrZero = {{0, 0, 0, 0}};
+
+typedef std::vector<Fr> FrVec;
+
+// go/bp/util.go:29-49, 106-163
+FrVec ntharr(const Fr& val, int n) {
+  FrVec r(n);
+  r[0] = kFrOne;
+  for (int i = 1; i < n; i++) r[i] = mul(r[i - 1], val);
+  return r;
+}
+FrVec invntharr(const Fr& val, int n) { return ntharr(fr_inv(val), n); }
+FrVec ones(int n) { return FrVec(n, kFrOne); }
+FrVec vectorAdd(const FrVec& a, const FrVec& b) {
+  if (a.size() != b.size()) throw std::runtime_error("invalid length");
+  FrVec r(a.size());
+  for (size_t i = 0; i < a.size(); i++) r[i] = add(a[i], b[i]);
+  return r;
+}
+FrVec vectorSub(const FrVec& a, const FrVec& b) {
+  if (a.size() != b.size()) throw std::runtime_error("invalid length");
+  FrVec r(a.size());
+  for (size_t i = 0; i < a.size(); i++) r[i] = sub(a[i], b[i]);
+  return r;
+}
+FrVec vectorMulOnScalar(const FrVec& a, const Fr& c) {
+  FrVec r(a.size());
+  for (size_t i = 0; i < a.size(); i++) r[i] = mul(a[i], c);
+  return r;
+}
+Fr vectorMul(const FrVec& a, const FrVec& b) {
+  if (a.size() != b.size()) throw std::runtime_error("invalid length");
+  Fr r = kFrZero;
+  for (size_t i = 0; i < a.size(); i++) r = add(r, mul(a[i], b[i]));
+  return r;
+}
+FrVec hadamardMul(const FrVec& a, const FrVec& b) {
+  if (a.size() != b.size()) throw std::runtime_error("invalid length");
+  FrVec r(a.size());
+  for (size_t i = 0; i < a.size(); i++) r[i] = mul(a[i], b[i]);
+  return r;
+}
+FrVec slice(const FrVec& a, size_t lo, size_t hi) { return FrVec(a.begin() + lo, a.begin() + hi); }
+
+// ------------------------------------------------------------------ Keccak-256 (legacy padding)
+// iden3 keccak256.Hash as used by hash(), go/bp/util.go:222-233.
+uint64_t rol64(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+void keccak_f1600(uint64_t s[25]) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+      0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+      0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  static const int piln[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+  static const int rotc[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+  for (int round = 0; round < 24; round++) {
+    uint64_t bc[5];
+    for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+    for (int i = 0; i < 5; i++) {
+      uint64_t t = bc[(i + 4) % 5] ^ rol64(bc[(i + 1) % 5], 1);
+      for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+    }
+    uint64_t t = s[1];
+    for (int i = 0; i < 24; i++) {
+      int j = piln[i];
+      uint64_t b = s[j];
+      s[j] = rol64(t, rotc[i]);
+      t = b;
+    }
+    for (int j = 0; j < 25; j += 5) {
+      for (int i = 0; i < 5; i++) bc[i] = s[j + i];
+      for (int i = 0; i < 5; i++) s[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+    }
+    s[0] ^= RC[round];
+  }
+}
+void keccak256(uint8_t out[32], const std::vector<uint8_t>& in) {
+  uint64_t s[25] = {0};
+  std::vector<uint8_t> m(in);
+  m.push_back(0x01);
+  while (m.size() % 136) m.push_back(0);
+  m.back() |= 0x80;
+  for (size_t off = 0; off < m.size(); off += 136) {
+    for (int i = 0; i < 17; i++) {
+      uint64_t w = 0;
+      for (int k = 7; k >= 0; k--) w = (w << 8) | m[off + 8 * i + k];
+      s[i] ^= w;
+    }
+    keccak_f1600(s);
+  }
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(s[i] >> (8 * k));
+}
+
+// ------------------------------------------------------------------ points on the host
+typedef std::vector<uint8_t> Bytes;  // a marshalled G1 point (64 bytes)
+
+struct Point {
+  uint8_t b[64];
+};
+Point pt_from(const hostg1::Pt& p) {
+  Point r;
+  hostg1::marshal(r.b, p);
+  return r;
+}
+hostg1::Pt pt_load(const Point& p) {
+  hostg1::Pt r;
+  if (hostg1::unmarshal(r, p.b)) throw std::runtime_error("bn256: malformed point");
+  return r;
+}
+// new(bn256.G1).ScalarMult(p, k) for single points: host double-and-add (com() stays on the CPU,
+// SURVEY.md 8a row a5)
+Point scalarMult(const Point& p, const Fr& k) {
+  uint64_t w[4];
+  fr_to_raw(w, k);
+  hostg1::Pt base = pt_load(p), acc = hostg1::infinity();
+  for (int i = 255; i >= 0; i--) {
+    acc = hostg1::dbl(acc);
+    if ((w[i >> 6] >> (i & 63)) & 1) acc = hostg1::padd(acc, base);
+  }
+  return pt_from(acc);
+}
+Point pointAdd(const Point& a, const Point& b) { return pt_from(hostg1::padd(pt_load(a), pt_load(b))); }
+bool pointEq(const Point& a, const Point& b) { return memcmp(a.b, b.b, 64) == 0; }  // bytes.Equal(Marshal, Marshal)
+// com(), go/bp/util.go:92-94
+Point com(const Point& g, const Point& h, const Fr& a, const Fr& b) { return pointAdd(scalarMult(g, a), scalarMult(h, b)); }
+
+// hash(), go/bp/util.go:222-233
+Fr hashFS(const FrVec& scalars, const std::vector<Point>& points) {
+  std::vector<uint8_t> data;
+  for (const Fr& s : scalars) {
+    uint8_t b[32];
+    fr_to_be(b, s);
+    data.insert(data.end(), b, b + 32);
+  }
+  for (const Point& p : points) data.insert(data.end(), p.b, p.b + 64);
+  uint8_t d[32];
+  keccak256(d, data);
+  return fr_from_be(d);
+}
+
+// ------------------------------------------------------------------ crypto/rand stand-in
+// rand.Reader replacement for deterministic transcripts: SplitMix64, 8 bytes
+// big-endian per step; rand.Int = read 32 bytes, accept iff < Order.
+struct ByteStream {
+  uint64_t s;
+  uint64_t next64() {
+    s += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+  }
+  Fr randInt(uint8_t raw_be[32] = nullptr) {
+    for (;;) {
+      uint64_t w[4];
+      for (int i = 3; i >= 0; i--) w[i] = next64();  // big-endian stream: first word is the most significant
+      if (!geq_n(w)) {
+        if (raw_be) hostg1::be_store(raw_be, w);
+        return fr_from_raw(w);
+      }
+    }
+  }
+  FrVec values(int n) {  // go/bp/util.go:51-63
+    FrVec r(n);
+    for (int i = 0; i < n; i++) r[i] = randInt();
+    return r;
+  }
+  Fr randNonZero(uint8_t raw_be[32]) {  // the k of bn256.RandomG1
+    for (;;) {
+      Fr k = randInt(raw_be);
+      bool z = true;
+      for (int i = 0; i < 32; i++) z = z && raw_be[i] == 0;
+      if (!z) return k;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ device vectors
+void chk(int rc) {
+  if (rc) throw std::runtime_error(bn256_strerror(rc));
+}
+struct DevPoints {  // a []*bn256.G1 resident in HBM
+  bn256_ctx* ctx = nullptr;
+  bn256_bases* h = nullptr;
+  size_t n = 0;
+  DevPoints() {}
+  DevPoints(bn256_ctx* c, bn256_bases* b) : ctx(c), h(b), n(bn256_bases_len(b)) {}
+  DevPoints(const DevPoints&) = delete;
+  DevPoints& operator=(const DevPoints&) = delete;
+  DevPoints(DevPoints&& o) noexcept : ctx(o.ctx), h(o.h), n(o.n) { o.h = nullptr; }
+  DevPoints& operator=(DevPoints&& o) noexcept {
+    if (this != &o) {
+      if (h) bn256_bases_free(ctx, h);
+      ctx = o.ctx; h = o.h; n = o.n; o.h = nullptr;
+    }
+    return *this;
+  }
+  ~DevPoints() {
+    if (h) bn256_bases_free(ctx, h);
+  }
+  Point at(size_t i) const {
+    Point p;
+    chk(bn256_bases_download(ctx, h, i, 1, p.b));
+    return p;
+  }
+};
+std::vector<uint8_t> scalarBytes(const FrVec& a) {
+  std::vector<uint8_t> s(32 * a.size());
+  for (size_t i = 0; i < a.size(); i++) fr_to_be(&s[32 * i], a[i]);
+  return s;
+}
+struct Seg {
+  const DevPoints* g;
+  size_t off;
+  FrVec a;
+};
+// sum of vectorPointScalarMul over segments (go/bp/util.go:165-175): one bn256_msm_multi
+Point msmSegments(bn256_ctx* ctx, const std::vector<Seg>& segs) {
+  std::vector<const bn256_bases*> hs;
+  std::vector<size_t> offs, ns;
+  std::vector<std::vector<uint8_t>> raws;
+  std::vector<const uint8_t*> ptrs;
+  for (const Seg& s : segs) {
+    if (s.off + s.a.size() > s.g->n) throw std::runtime_error("invalid length for scalar mul");
+    hs.push_back(s.g->h);
+    offs.push_back(s.off);
+    ns.push_back(s.a.size());
+    raws.push_back(scalarBytes(s.a));
+  }
+  for (auto& r : raws) ptrs.push_back(r.data());
+  Point out;
+  chk(bn256_msm_multi(ctx, (int)segs.size(), hs.data(), offs.data(), ns.data(), ptrs.data(), out.b));
+  return out;
+}
+// vectorPointScalarMul, go/bp/util.go:165-175
+Point vectorPointScalarMul(bn256_ctx* ctx, const DevPoints& g, size_t off, size_t len, const FrVec& a) {
+  if (len != a.size()) throw std::runtime_error("invalid length for scalar mul");
+  return msmSegments(ctx, {{&g, off, a}});
+}
+
+// ------------------------------------------------------------------ go/bp/main.go
+struct InnerArgumentPublic {  // go/bp/main.go:38-45
+  int N;
+  DevPoints G, H;
+  Point U;
+};
+struct InnerProductProof {  // go/bp/main.go:253-260
+  std::vector<Point> L, R;
+  Fr A, B;
+};
+
+// innerArgProof, go/bp/main.go:321-377 (recursion unrolled into a loop; G, H stay on device)
+InnerProductProof innerArgProof(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, FrVec a, FrVec b) {
+  InnerProductProof proof;
+  while (N != 1) {
+    if (N % 2 != 0) throw std::runtime_error("invalid n: should be 2^x");
+    size_t n1 = N / 2;
+    FrVec alo = slice(a, 0, n1), ahi = slice(a, n1, N), blo = slice(b, 0, n1), bhi = slice(b, n1, N);
+    Fr cl = vectorMul(alo, bhi), cr = vectorMul(ahi, blo);
+    // L = vecCom(G[n1:], H[:n1], a[:n1], b[n1:]) + cl*U ;  R = vecCom(G[:n1], H[n1:], a[n1:], b[:n1]) + cr*U
+    Point L = pointAdd(msmSegments(ctx, {{&G, n1, alo}, {&H, 0, bhi}}), scalarMult(U, cl));
+    Point R = pointAdd(msmSegments(ctx, {{&G, 0, ahi}, {&H, n1, blo}}), scalarMult(U, cr));
+    // P = productCom(G, H, U, a, b), go/bp/util.go:100-104 (recomputed at every level, main.go:347)
+    Point P = pointAdd(msmSegments(ctx, {{&G, 0, a}, {&H, 0, b}}), scalarMult(U, vectorMul(a, b)));
+    proof.L.push_back(L);
+    proof.R.push_back(R);
+    Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, L, R});
+    Fr xinv = fr_inv(x);
+    // g1 = xinv*G[:n1] (+) x*G[n1:] ; h1 = x*H[:n1] (+) xinv*H[n1:]   (main.go:355-356), fused on device
+    uint8_t xb[32], xib[32];
+    fr_to_be(xb, x);
+    fr_to_be(xib, xinv);
+    bn256_bases *g1 = nullptr, *h1 = nullptr;
+    chk(bn256_fold(ctx, G.h, 0, G.h, n1, 1, n1, xib, xb, &g1));
+    DevPoints G1(ctx, g1);
+    chk(bn256_fold(ctx, H.h, 0, H.h, n1, 1, n1, xb, xib, &h1));
+    DevPoints H1(ctx, h1);
+    FrVec a1 = vectorAdd(vectorMulOnScalar(alo, x), vectorMulOnScalar(ahi, xinv));
+    FrVec b1 = vectorAdd(vectorMulOnScalar(bhi, x), vectorMulOnScalar(blo, xinv));
+    G = std::move(G1);
+    H = std::move(H1);
+    a = a1;
+    b = b1;
+    N = (int)n1;
+  }
+  proof.A = a[0];
+  proof.B = b[0];
+  return proof;
+}
+
+// innerArgVerify, go/bp/main.go:273-319.  Returns "" on success or the reference's error text.
+std::string innerArgVerify(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, Point P,
+                           const InnerProductProof& proof) {
+  size_t deep = 0;
+  while (N != 1) {
+    if (N % 2 != 0) return "invalid n: should be 2^x";
+    if (deep >= proof.L.size() || deep >= proof.R.size()) return "failed to verify inner argument proof";
+    size_t n1 = N / 2;
+    Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, proof.L[deep], proof.R[deep]});
+    Fr xinv = fr_inv(x), x2 = mul(x, x), x2inv = fr_inv(x2);
+    uint8_t xb[32], xib[32];
+    fr_to_be(xb, x);
+    fr_to_be(xib, xinv);
+    bn256_bases *g1 = nullptr, *h1 = nullptr;
+    chk(bn256_fold(ctx, G.h, 0, G.h, n1, 1, n1, xib, xb, &g1));
+    DevPoints G1(ctx, g1);
+    chk(bn256_fold(ctx, H.h, 0, H.h, n1, 1, n1, xb, xib, &h1));
+    DevPoints H1(ctx, h1);
+    P = pointAdd(pointAdd(scalarMult(proof.L[deep], x2), P), scalarMult(proof.R[deep], x2inv));
+    G = std::move(G1);
+    H = std::move(H1);
+    N = (int)n1;
+    deep++;
+  }
+  Point p = pointAdd(com(G.at(0), H.at(0), proof.A, proof.B), scalarMult(U, mul(proof.A, proof.B)));
+  if (!pointEq(P, p)) return "failed to verify inner argument proof";
+  return "";
+}
+
+struct BulletProofPublic {  // go/bp/main.go:17-24
+  int N;
+  DevPoints G, H;  // InnerArgumentPublic.G / .H
+  Point U;
+  Point g, h;  // commitment bases
+};
+struct BulletProof {  // go/bp/main.go:59-78
+  Point V, ACom, SCom, T1Com, T2Com;
+  Fr Tx, TauX, Nu;
+  std::vector<Point> L, R;
+  Fr A, B;
+};
+
+// points(n), go/bp/util.go:81-90, with RandomG1 = k*G0: the k are drawn on the host from the
+// injected reader, the n base multiplications run on the device.
+DevPoints points(bn256_ctx* ctx, ByteStream& rd, int n) {
+  std::vector<uint8_t> ks(32 * (size_t)n), g0(64 * (size_t)n, 0);
+  uint64_t y[4] = {hostg1::kP[0] - 2, hostg1::kP[1], hostg1::kP[2], hostg1::kP[3]};
+  for (int i = 0; i < n; i++) {
+    rd.randNonZero(&ks[32 * (size_t)i]);
+    g0[64 * (size_t)i + 31] = 1;
+    hostg1::be_store(&g0[64 * (size_t)i + 32], y);
+  }
+  bn256_bases *gen = nullptr, *out = nullptr;
+  chk(bn256_bases_upload(ctx, g0.data(), (size_t)n, 0, &gen));
+  DevPoints G0s(ctx, gen);
+  chk(bn256_scalar_mul_batch(ctx, gen, 0, (size_t)n, ks.data(), 0, &out));
+  return DevPoints(ctx, out);
+}
+
+// NewBulletProofPublic, go/bp/main.go:27-34 (draw order: G[0..n), H[0..n), U, g, h)
+BulletProofPublic newBulletProofPublic(bn256_ctx* ctx, ByteStream& rd, int n) {
+  BulletProofPublic p;
+  p.N = n;
+  p.G = points(ctx, rd, n);
+  p.H = points(ctx, rd, n);
+  p.U = points(ctx, rd, 1).at(0);
+  p.g = points(ctx, rd, 1).at(0);
+  p.h = points(ctx, rd, 1).at(0);
+  return p;
+}
+
+FrVec toBits(const Fr& v, int n) {  // go/bp/util.go:235-251
+  uint64_t w[4];
+  fr_to_raw(w, v);
+  FrVec r(n, kFrZero);
+  for (int i = 0; i < n && i < 256; i++)
+    if ((w[i >> 6] >> (i & 63)) & 1) r[i] = kFrOne;
+  return r;
+}
+
+DevPoints cloneRange(bn256_ctx* ctx, const DevPoints& g) {  // a second handle on the same points
+  std::vector<uint8_t> raw(64 * g.n);
+  chk(bn256_bases_download(ctx, g.h, 0, g.n, raw.data()));
+  bn256_bases* h = nullptr;
+  chk(bn256_bases_upload(ctx, raw.data(), g.n, 0, &h));
+  return DevPoints(ctx, h);
+}
+
+// (*BulletProofPublic).Prove, go/bp/main.go:81-178.  Randomness order: alpha, sl, sr, ro, tau1, tau2.
+BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const Fr& prv, ByteStream& rd) {
+  const int N = p.N;
+  FrVec onen = ones(N);
+  FrVec al = toBits(v, N);
+  FrVec ar = vectorSub(al, onen);
+  Fr alpha = rd.values(1)[0];
+  Point A = pointAdd(msmSegments(ctx, {{&p.G, 0, al}, {&p.H, 0, ar}}), scalarMult(p.h, alpha));
+  FrVec sl = rd.values(N), sr = rd.values(N);
+  Fr ro = rd.values(1)[0];
+  Point S = pointAdd(msmSegments(ctx, {{&p.G, 0, sl}, {&p.H, 0, sr}}), scalarMult(p.h, ro));
+  Point V = com(p.g, p.h, v, prv);
+  BulletProof proof;
+  proof.V = V;
+  proof.ACom = A;
+  proof.SCom = S;
+  Fr y = hashFS({fr_from_u64((uint64_t)N)}, {A, S, V});
+  Fr z = hashFS({y}, {A, S});
+  FrVec yn = ntharr(y, N);
+  Fr z2 = mul(z, z);
+  FrVec twon = ntharr(fr_from_u64(2), N);
+  Fr t1 = add(vectorMul(hadamardMul(yn, sr), vectorSub(al, vectorMulOnScalar(onen, z))),
+              vectorMul(sl, vectorAdd(vectorMulOnScalar(twon, z2),
+                                      hadamardMul(yn, vectorAdd(ar, vectorMulOnScalar(onen, z))))));
+  Fr t2 = vectorMul(hadamardMul(yn, sr), sl);
+  Fr tau1 = rd.values(1)[0], tau2 = rd.values(1)[0];
+  proof.T1Com = com(p.g, p.h, t1, tau1);
+  proof.T2Com = com(p.g, p.h, t2, tau2);
+  Fr x = hashFS({y, z}, {proof.T1Com, proof.T2Com});
+  Fr x2 = mul(x, x);
+  FrVec l = vectorAdd(vectorSub(al, vectorMulOnScalar(onen, z)), vectorMulOnScalar(sl, x));
+  FrVec r = vectorAdd(
+      hadamardMul(yn, vectorAdd(ar, vectorAdd(vectorMulOnScalar(onen, z), vectorMulOnScalar(sr, x)))),
+      vectorMulOnScalar(twon, z2));
+  proof.Tx = vectorMul(l, r);
+  proof.TauX = add(mul(tau2, x2), add(mul(tau1, x), mul(z2, prv)));
+  proof.Nu = add(alpha, mul(ro, x));
+  // h1[i] = H[i] * yinvn[i]   (main.go:156-159), batched on device
+  FrVec yinvn = invntharr(y, N);
+  std::vector<uint8_t> yb = scalarBytes(yinvn);
+  bn256_bases* h1 = nullptr;
+  chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &h1));
+  InnerProductProof ip = innerArgProof(ctx, N, cloneRange(ctx, p.G), DevPoints(ctx, h1), p.U, l, r);
+  proof.A = ip.A;
+  proof.B = ip.B;
+  proof.L = ip.L;
+  proof.R = ip.R;
+  return proof;
+}
+
+// (*BulletProofPublic).Verify, go/bp/main.go:181-249
+std::string verify(bn256_ctx* ctx, const BulletProofPublic& p, const BulletProof& proof) {
+  const int N = p.N;
+  Fr y = hashFS({fr_from_u64((uint64_t)N)}, {proof.ACom, proof.SCom, proof.V});
+  Fr z = hashFS({y}, {proof.ACom, proof.SCom});
+  FrVec yn = ntharr(y, N);
+  Fr z2 = mul(z, z), z3 = mul(z2, z);
+  FrVec onen = ones(N), twon = ntharr(fr_from_u64(2), N);
+  Fr x = hashFS({y, z}, {proof.T1Com, proof.T2Com});
+  Fr x2 = mul(x, x);
+  FrVec yinvn = invntharr(y, N);
+  std::vector<uint8_t> yb = scalarBytes(yinvn);
+  bn256_bases* h1raw = nullptr;
+  chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &h1raw));
+  DevPoints h1(ctx, h1raw);
+  Fr deltayz = sub(mul(sub(z, z2), vectorMul(onen, yn)), mul(z3, vectorMul(onen, twon)));
+  Point c1 = com(p.g, p.h, proof.Tx, proof.TauX);
+  Point c2 = scalarMult(proof.V, z2);
+  c2 = pointAdd(c2, scalarMult(p.g, deltayz));
+  c2 = pointAdd(c2, scalarMult(proof.T1Com, x));
+  c2 = pointAdd(c2, scalarMult(proof.T2Com, x2));
+  if (!pointEq(c1, c2)) return "failed: tx ?= t0 + t1*x +t2*x^2";
+  Point P = pointAdd(proof.ACom, scalarMult(proof.SCom, x));
+  P = pointAdd(P, vectorPointScalarMul(ctx, p.G, 0, (size_t)N, vectorMulOnScalar(onen, sub(kFrZero, z))));
+  P = pointAdd(P, vectorPointScalarMul(ctx, h1, 0, (size_t)N,
+                                       vectorAdd(vectorMulOnScalar(yn, z), vectorMulOnScalar(twon, z2))));
+  P = pointAdd(P, scalarMult(p.h, sub(kFrZero, proof.Nu)));
+  P = pointAdd(P, scalarMult(p.U, proof.Tx));
+  InnerProductProof ip;
+  ip.L = proof.L;
+  ip.R = proof.R;
+  ip.A = proof.A;
+  ip.B = proof.B;
+  return innerArgVerify(ctx, N, cloneRange(ctx, p.G), std::move(h1), p.U, P, ip);
+}
+
+// ------------------------------------------------------------------ wire format
+// V, A, S, T1, T2 (64 B each) | tx, taux, nu (32 B each) | u32 BE k | L[k], R[k] (64 B each) | a, b (32 B)
+std::vector<uint8_t> serialize(const BulletProof& pr) {
+  std::vector<uint8_t> o;
+  auto pt = [&](const Point& p) { o.insert(o.end(), p.b, p.b + 64); };
+  auto sc = [&](const Fr& s) {
+    uint8_t b[32];
+    fr_to_be(b, s);
+    o.insert(o.end(), b, b + 32);
+  };
+  pt(pr.V); pt(pr.ACom); pt(pr.SCom); pt(pr.T1Com); pt(pr.T2Com);
+  sc(pr.Tx); sc(pr.TauX); sc(pr.Nu);
+  uint32_t k = (uint32_t)pr.L.size();
+  o.push_back((uint8_t)(k >> 24)); o.push_back((uint8_t)(k >> 16)); o.push_back((uint8_t)(k >> 8)); o.push_back((uint8_t)k);
+  for (const Point& p : pr.L) pt(p);
+  for (const Point& p : pr.R) pt(p);
+  sc(pr.A); sc(pr.B);
+  return o;
+}
+bool deserialize(BulletProof& pr, const uint8_t* in, size_t len) {
+  size_t pos = 0;
+  auto pt = [&](Point& p) {
+    if (pos + 64 > len) return false;
+    memcpy(p.b, in + pos, 64);
+    pos += 64;
+    hostg1::Pt t;
+    return hostg1::unmarshal(t, p.b) == 0;
+  };
+  auto sc = [&](Fr& s) {
+    if (pos + 32 > len) return false;
+    uint64_t w[4];
+    hostg1::be_load(w, in + pos);
+    if (geq_n(w)) return false;
+    s = fr_from_raw(w);
+    pos += 32;
+    return true;
+  };
+  if (!pt(pr.V) || !pt(pr.ACom) || !pt(pr.SCom) || !pt(pr.T1Com) || !pt(pr.T2Com)) return false;
+  if (!sc(pr.Tx) || !sc(pr.TauX) || !sc(pr.Nu)) return false;
+  if (pos + 4 > len) return false;
+  uint32_t k = ((uint32_t)in[pos] << 24) | ((uint32_t)in[pos + 1] << 16) | ((uint32_t)in[pos + 2] << 8) | in[pos + 3];
+  pos += 4;
+  if (k > 64) return false;
+  pr.L.resize(k);
+  pr.R.resize(k);
+  for (uint32_t i = 0; i < k; i++)
+    if (!pt(pr.L[i])) return false;
+  for (uint32_t i = 0; i < k; i++)
+    if (!pt(pr.R[i])) return false;
+  if (!sc(pr.A) || !sc(pr.B)) return false;
+  return pos == len;
+}
+
+thread_local std::string g_err;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- C exports
+extern "C" const char* bp_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bp_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]) {
+  std::vector<uint8_t> m(msg, msg + len);
+  keccak256(out, m);
+  return 0;
+}
+
+extern "C" int bp_prove_det(bn256_ctx* ctx, int n, const uint8_t v_be[32], uint64_t seed, uint8_t* out, size_t cap,
+                            size_t* out_len) {
+  try {
+    if (!ctx || !v_be || !out || !out_len || n < 1) return BN256_EINVAL;
+    ByteStream rd{seed};
+    BulletProofPublic pub = newBulletProofPublic(ctx, rd, n);
+    Fr prv = rd.values(1)[0];  // test harness draws prv before Prove (go/bp/main_test.go:20)
+    BulletProof pr = prove(ctx, pub, fr_from_be(v_be), prv, rd);
+    std::vector<uint8_t> ser = serialize(pr);
+    *out_len = ser.size();
+    if (ser.size() > cap) return BN256_ELENGTH;
+    memcpy(out, ser.data(), ser.size());
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}
+
+extern "C" int bp_verify_det(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t* proof, size_t len) {
+  try {
+    if (!ctx || !proof || n < 1) return BN256_EINVAL;
+    ByteStream rd{seed};
+    BulletProofPublic pub = newBulletProofPublic(ctx, rd, n);
+    BulletProof pr;
+    if (!deserialize(pr, proof, len)) {
+      g_err = "malformed proof encoding";
+      return BP_EFAIL;
+    }
+    std::string e = verify(ctx, pub, pr);
+    g_err = e;
+    return e.empty() ? 0 : BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}
+
+// Inner-product argument on its own (InnerArgumentPublic.Prove / Verify, go/bp/main.go:263-271):
+// generators from the seed (G[n], H[n], U), a and b given; returns P || L.. || R.. || a || b.
+extern "C" int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t* a_be, const uint8_t* b_be,
+                                          int tamper) {
+  try {
+    if (!ctx || !a_be || !b_be || n < 1) return BN256_EINVAL;
+    ByteStream rd{seed};
+    DevPoints G = points(ctx, rd, n), H = points(ctx, rd, n);
+    Point U = points(ctx, rd, 1).at(0);
+    FrVec a(n), b(n);
+    for (int i = 0; i < n; i++) {
+      a[i] = fr_from_be(a_be + 32 * i);
+      b[i] = fr_from_be(b_be + 32 * i);
+    }
+    Point P = pointAdd(msmSegments(ctx, {{&G, 0, a}, {&H, 0, b}}), scalarMult(U, vectorMul(a, b)));
+    InnerProductProof ip = innerArgProof(ctx, n, cloneRange(ctx, G), cloneRange(ctx, H), U, a, b);
+    if (tamper) ip.A = add(ip.A, kFrOne);
+    std::string e = innerArgVerify(ctx, n, std::move(G), std::move(H), U, P, ip);
+    g_err = e;
+    return e.empty() ? 0 : BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}

@@ -1,0 +1,45 @@
+/*
+ * libbpamd -- host-side mirror of olegfomenko/crypto's go/bp (Bulletproofs range proof +
+ * inner-product argument) on top of libbn256msm.  The Go toolchain is absent from the build
+ * image, so the host layer above the C ABI is C++ (crypto_amd/csrc/bp_host.cpp) with the
+ * reference's function names inside; these C entry points exist so the tests can drive it.
+ *
+ * Randomness is injected (the reference draws from crypto/rand, go/bp/util.go:51-63,81-90):
+ * `seed` starts a SplitMix64 byte stream that stands in for rand.Reader, consumed in the
+ * reference's order, so transcripts are reproducible and comparable
+ * byte-for-byte with the oracle's.
+ */
+#ifndef BP_AMD_H
+#define BP_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#include "bn256msm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_EFAIL (-20)   /* exception text in bp_last_error() */
+#define BP_EVERIFY (-21) /* Verify returned an error; the reference's message in bp_last_error() */
+
+/* NewBulletProofPublic(n) from the seeded reader, prv := next rand.Int, then
+ * (*BulletProofPublic).Prove(v, prv) -- go/bp/main.go:27-34, :81-178, go/bp/main_test.go:16-36.
+ * Wire format of the proof (the reference defines none; BulletProof struct go/bp/main.go:59-78):
+ *   V, A, S, T1, T2 (64 B each) | tx, taux, nu (32 B BE each) | u32 BE k | L[k], R[k] (64 B each) | a, b (32 B) */
+int bp_prove_det(bn256_ctx* ctx, int n, const uint8_t v_be[32], uint64_t seed, uint8_t* out, size_t cap, size_t* out_len);
+
+/* (*BulletProofPublic).Verify -- go/bp/main.go:181-249; public parameters regenerated from the seed.
+ * 0 = accepted, BP_EVERIFY = rejected (reference error string in bp_last_error()). */
+int bp_verify_det(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t* proof, size_t len);
+
+/* InnerArgumentPublic.Prove + Verify round trip -- go/bp/main.go:263-377 (TestInnerArgumentProof shape). */
+int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t* a_be, const uint8_t* b_be, int tamper);
+
+/* hash()'s digest function: legacy Keccak-256 -- go/bp/util.go:232. */
+int bp_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]);
+
+const char* bp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

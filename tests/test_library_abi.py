@@ -64,3 +64,22 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_bp_library_exports_and_keccak(golden):
+    """libbpamd.so (include/bp_amd.h) loads, exports every declared symbol; Keccak is host-only."""
+    import ctypes as C
+    from crypto_amd import bp
+    lib = bp.load()
+    txt = open(os.path.join(ROOT, "include", "bp_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", txt)))
+    assert names == sorted(bp.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+    out = C.create_string_buffer(32)
+    for e in golden["keccak256"]:
+        m = bytes.fromhex(e["msg"])
+        lib.bp_keccak256(m, len(m), out)
+        assert out.raw.hex() == e["digest"]
+    assert lib.bp_prove_det(None, 4, None, 0, None, 0, None) == -1
