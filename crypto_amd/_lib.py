@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libbn256msm.so")
 
 EXPORTS = [
     "bn256_ctx_create", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
-    "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_multi", "bn256_scalar_mul_batch",
+    "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_multi", "bn256_msm_multi_strided", "bn256_fold2", "bn256_scalar_mul_batch",
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
 ]
@@ -49,6 +49,9 @@ def load() -> C.CDLL:
     lib.bn256_msm.argtypes = [vp, vp, sz, sz, u8p, u8p]
     lib.bn256_msm_dev.argtypes = [vp, vp, sz, sz, vp, u8p]
     lib.bn256_msm_multi.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p), u8p]
+    lib.bn256_msm_multi_strided.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
+                                            C.POINTER(u8p), u8p]
+    lib.bn256_fold2.argtypes = [vp, vp, sz, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp)]
     lib.bn256_scalar_mul_batch.argtypes = [vp, vp, sz, sz, u8p, i, C.POINTER(vp)]
     lib.bn256_add_batch.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(vp)]
     lib.bn256_fold.argtypes = [vp, vp, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp)]

@@ -8,7 +8,8 @@ from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbpamd.so")
-EXPORTS = ["bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error"]
+EXPORTS = ["bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
+           "bp_wnla_det", "bp_wnla_synthetic"]
 _bp = None
 
 
@@ -24,6 +25,9 @@ def load() -> C.CDLL:
     lib.bp_prove_det.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, sz, C.POINTER(sz)]
     lib.bp_verify_det.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, sz]
     lib.bp_inner_product_roundtrip.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int]
+    lib.bp_wnla_det.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
+    lib.bp_wnla_synthetic.argtypes = [vp, C.c_uint64, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int)]
     lib.bp_keccak256.argtypes = [C.c_char_p, sz, C.c_char_p]
     lib.bp_last_error.restype = C.c_char_p
     _bp = lib
@@ -60,6 +64,46 @@ class BulletProofs:
         if rc == 0:
             return None
         return self.lib.bp_last_error().decode()
+
+
+class WNLA:
+    """wnla / TestWNLA of go/bppp/docs_test.go:1242-1338 over the device library."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.lib = load()
+
+    def run(self, seed: int, l, n) -> dict:
+        cap = 1 << 16
+        out = C.create_string_buffer(cap)
+        ln = C.c_size_t(0)
+        rc = self.lib.bp_wnla_det(self.eng.ctx, seed, len(l), len(n),
+                                  b"".join(int(x).to_bytes(32, "big") for x in l),
+                                  b"".join(int(x).to_bytes(32, "big") for x in n), out, cap, C.byref(ln))
+        if rc not in (0, -21):
+            raise RuntimeError(f"bp_wnla_det rc={rc}: {self.lib.bp_last_error().decode()}")
+        raw = out.raw[:ln.value]
+        pos = 64
+        res = {"C": raw[:64].hex(), "ok": rc == 0, "rounds": []}
+        k = int.from_bytes(raw[pos:pos + 4], "big")
+        pos += 4
+        for _ in range(k):
+            res["rounds"].append((raw[pos:pos + 64].hex(), raw[pos + 64:pos + 128].hex()))
+            pos += 128
+        for key in ("l", "n"):
+            k = int.from_bytes(raw[pos:pos + 4], "big")
+            pos += 4
+            res[key] = [int.from_bytes(raw[pos + 32 * i:pos + 32 * i + 32], "big") for i in range(k)]
+            pos += 32 * k
+        assert pos == len(raw)
+        return res
+
+    def synthetic(self, seed: int, nl: int, nn: int) -> dict:
+        ms0, ms1, rounds = C.c_double(0), C.c_double(0), C.c_int(0)
+        rc = self.lib.bp_wnla_synthetic(self.eng.ctx, seed, nl, nn, C.byref(ms0), C.byref(ms1), C.byref(rounds))
+        if rc not in (0, -21):
+            raise RuntimeError(f"bp_wnla_synthetic rc={rc}: {self.lib.bp_last_error().decode()}")
+        return {"ok": rc == 0, "ms_setup": ms0.value, "ms_run": ms1.value, "rounds": rounds.value}
 
 
 def parse_proof(raw: bytes) -> dict:

@@ -254,8 +254,8 @@ extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t
 // ---------------------------------------------------------------------------- MSM core
 // Runs the device pipeline for one contiguous range with device-resident scalars and returns
 // the XYZZ sum as a host point.
-static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* d_scalars,
-                    hostg1::Pt* result) {
+static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
+                    const uint8_t* d_scalars, hostg1::Pt* result) {
   using namespace hostg1;
   *result = infinity();
   for (float& f : ctx->last_ms) f = 0.f;
@@ -323,14 +323,14 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
   if (use_lds) {
     hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
-                       (u32)W, nb, (u32)precomp, (u32)off, (u32)b->n, tile_len, hist, (const u32*)nullptr,
+                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, hist, (const u32*)nullptr,
                        (u32*)nullptr);
     HIPCHK(hipEventRecord(ctx->ev[1], s));
     hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
   } else {
     HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
     hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                       (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)nullptr, (u32*)nullptr);
+                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, counts, rank, (const u32*)nullptr, (u32*)nullptr);
     HIPCHK(hipEventRecord(ctx->ev[1], s));
   }
   // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
@@ -340,10 +340,10 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   HIPCHK(hipEventRecord(ctx->ev[2], s));
   if (use_lds) {
     hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
-                       (u32)W, nb, (u32)precomp, (u32)off, (u32)b->n, tile_len, hist, (const u32*)offsets, sval);
+                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, hist, (const u32*)offsets, sval);
   } else {
     hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                       (u32)precomp, (u32)off, (u32)b->n, counts, rank, (const u32*)offsets, sval);
+                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, counts, rank, (const u32*)offsets, sval);
   }
   HIPCHK(hipEventRecord(ctx->ev[3], s));
   hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
@@ -385,8 +385,12 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, 
   return BN256_OK;
 }
 
-static int range_check(const bn256_bases* b, size_t off, size_t n) {
-  if (off > b->n || n > b->n - off) return BN256_ELENGTH;
+static int range_check(const bn256_bases* b, size_t off, size_t n, size_t stride = 1) {
+  if (stride == 0) return BN256_EINVAL;
+  if (off > b->n) return BN256_ELENGTH;
+  if (n == 0) return BN256_OK;
+  size_t avail = b->n - off;              // need (n-1)*stride + 1 <= avail
+  if (avail == 0 || (n - 1) > (avail - 1) / stride) return BN256_ELENGTH;
   return BN256_OK;
 }
 
@@ -397,21 +401,21 @@ extern "C" int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, s
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt r;
-  rc = msm_core(ctx, b, off, n, (const uint8_t*)d_scalars_be, &r);
+  rc = msm_core(ctx, b, off, 1, n, (const uint8_t*)d_scalars_be, &r);
   if (rc) return rc;
   hostg1::marshal(out_xy_be, r);
   return BN256_OK;
 }
 
-static int msm_host_scalars(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
-                            hostg1::Pt* r) {
-  int rc = range_check(b, off, n);
+static int msm_host_scalars(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
+                            const uint8_t* scalars_be, hostg1::Pt* r) {
+  int rc = range_check(b, off, n, stride);
   if (rc) return rc;
   if (n) {
     if ((rc = ws_reserve(ctx, WS_SCALARS, n * 32))) return rc;
     HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, n * 32, hipMemcpyHostToDevice, ctx->stream));
   }
-  return msm_core(ctx, b, off, n, (const uint8_t*)ctx->ws[WS_SCALARS], r);
+  return msm_core(ctx, b, off, stride, n, (const uint8_t*)ctx->ws[WS_SCALARS], r);
 }
 
 extern "C" int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
@@ -419,14 +423,15 @@ extern "C" int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_
   if (!ctx || !b || !out_xy_be || (!scalars_be && n)) return BN256_EINVAL;
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt r;
-  int rc = msm_host_scalars(ctx, b, off, n, scalars_be, &r);
+  int rc = msm_host_scalars(ctx, b, off, 1, n, scalars_be, &r);
   if (rc) return rc;
   hostg1::marshal(out_xy_be, r);
   return BN256_OK;
 }
 
-extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
-                               const uint8_t* const* scalars_be, uint8_t out_xy_be[64]) {
+extern "C" int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                                       const size_t* stride, const size_t* n, const uint8_t* const* scalars_be,
+                                       uint8_t out_xy_be[64]) {
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt total = hostg1::infinity();
@@ -434,7 +439,7 @@ extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* 
   for (int i = 0; i < k; i++) {
     if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
     hostg1::Pt r;
-    int rc = msm_host_scalars(ctx, b[i], off[i], n[i], scalars_be[i], &r);
+    int rc = msm_host_scalars(ctx, b[i], off[i], stride ? stride[i] : 1, n[i], scalars_be[i], &r);
     if (rc) return rc;
     total = hostg1::padd(total, r);
     for (int j = 0; j < 7; j++) ms[j] += ctx->last_ms[j];
@@ -442,6 +447,11 @@ extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* 
   for (int j = 0; j < 7; j++) ctx->last_ms[j] = ms[j];
   hostg1::marshal(out_xy_be, total);
   return BN256_OK;
+}
+
+extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
+                               const uint8_t* const* scalars_be, uint8_t out_xy_be[64]) {
+  return bn256_msm_multi_strided(ctx, k, b, off, nullptr, n, scalars_be, out_xy_be);
 }
 
 // ---------------------------------------------------------------------------- element-wise
@@ -489,19 +499,16 @@ extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff
   return BN256_OK;
 }
 
-extern "C" int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256_bases* hi, size_t hi_off,
-                          size_t stride, size_t n, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
-                          bn256_bases** out) {
+extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                           size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32],
+                           const uint8_t s_hi_be[32], bn256_bases** out) {
   if (!ctx || !lo || !hi || !out || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
   *out = nullptr;
-  if (n) {
-    size_t span = (n - 1) * stride + 1;
-    int rc = range_check(lo, lo_off, span);
-    if (rc) return rc;
-    if ((rc = range_check(hi, hi_off, span))) return rc;
-  }
-  HIPCHK(hipSetDevice(ctx->device));
   int rc;
+  if ((rc = range_check(lo, lo_off, n_lo, stride))) return rc;
+  if ((rc = range_check(hi, hi_off, n_hi, stride))) return rc;
+  size_t n = std::max(n_lo, n_hi);
+  HIPCHK(hipSetDevice(ctx->device));
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
   if (n) {
@@ -512,13 +519,19 @@ extern "C" int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, 
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
                          (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride,
-                         (const uint8_t*)ds, (const uint8_t*)(ds + 32), r->d, (u32)n);
+                         (const uint8_t*)ds, (const uint8_t*)(ds + 32), r->d, (u32)n_lo, (u32)n_hi);
       e = hipStreamSynchronize(ctx->stream);
     }
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
   }
   *out = r;
   return BN256_OK;
+}
+
+extern "C" int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256_bases* hi, size_t hi_off,
+                          size_t stride, size_t n, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                          bn256_bases** out) {
+  return bn256_fold2(ctx, lo, lo_off, n, hi, hi_off, n, stride, s_lo_be, s_hi_be, out);
 }
 
 // ---------------------------------------------------------------------------- synthetic

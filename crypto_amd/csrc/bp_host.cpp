@@ -6,7 +6,9 @@
 //
 // This is product code; it shares nothing with oracle/.
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -653,6 +655,134 @@ bool deserialize(BulletProof& pr, const uint8_t* in, size_t len) {
   return pos == len;
 }
 
+// ------------------------------------------------------------------ go/bppp: weighted norm linear argument
+// BP++ helper semantics (go/bppp/util.go): pad-tolerant vector ops, even/odd reduction.
+FrVec padTo(FrVec a, size_t n) {
+  while (a.size() < n) a.push_back(kFrZero);
+  return a;
+}
+FrVec vectorAddPP(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:245-260
+  size_t n = std::max(a.size(), b.size());
+  return vectorAdd(padTo(a, n), padTo(b, n));
+}
+Fr vectorMulPP(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:143-157
+  size_t n = std::max(a.size(), b.size());
+  return vectorMul(padTo(a, n), padTo(b, n));
+}
+Fr weightVectorMul(const FrVec& a_in, const FrVec& b_in, const Fr& mu) {  // go/bppp/util.go:159-176
+  size_t n = std::max(a_in.size(), b_in.size());
+  FrVec a = padTo(a_in, n), b = padTo(b_in, n);
+  Fr res = kFrZero, e = mu;
+  for (size_t i = 0; i < n; i++) {
+    res = add(res, mul(mul(a[i], b[i]), e));
+    e = mul(e, mu);
+  }
+  return res;
+}
+void reduceVector(const FrVec& v, FrVec& v0, FrVec& v1) {  // go/bppp/util.go:198-211
+  v0.clear();
+  v1.clear();
+  for (size_t i = 0; i < v.size(); i++) (i % 2 == 0 ? v0 : v1).push_back(v[i]);
+}
+// values(n) of go/bppp/util.go:11-25: rand.Int is drawn and discarded, the value is 2
+FrVec valuesPP(ByteStream* rd, int n) {
+  FrVec r(n);
+  for (int i = 0; i < n; i++) {
+    if (rd) rd->randInt();
+    r[i] = fr_from_u64(2);
+  }
+  return r;
+}
+struct SSeg {
+  const DevPoints* g;
+  size_t off, stride, len;  // len = number of points of the (strided) view
+  FrVec a;
+};
+// sum of BP++ vectorPointScalarMul over strided views (go/bppp/util.go:178-196: empty view ->
+// identity, short scalar vectors zero-padded, long ones truncated)
+Point msmStrided(bn256_ctx* ctx, const std::vector<SSeg>& segs) {
+  std::vector<const bn256_bases*> hs;
+  std::vector<size_t> offs, strides, ns;
+  std::vector<std::vector<uint8_t>> raws;
+  std::vector<const uint8_t*> ptrs;
+  for (const SSeg& s : segs) {
+    size_t n = std::min(s.len, s.a.size());  // zero padding contributes nothing
+    if (n == 0) continue;
+    hs.push_back(s.g->h);
+    offs.push_back(s.off);
+    strides.push_back(s.stride);
+    ns.push_back(n);
+    raws.push_back(scalarBytes(slice(s.a, 0, n)));
+  }
+  for (auto& r : raws) ptrs.push_back(r.data());
+  Point out;
+  chk(bn256_msm_multi_strided(ctx, (int)hs.size(), hs.data(), offs.data(), strides.data(), ns.data(), ptrs.data(),
+                              out.b));
+  return out;
+}
+struct WnlaResult {
+  std::vector<Point> X, R;
+  FrVec l, n;
+  bool verified = false;
+};
+// wnla, go/bppp/docs_test.go:1269-1338 (recursion as a loop; G, H stay on device, the even/odd
+// halves of reducePoints are stride-2 views)
+WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, FrVec c, Point C, Fr ro, Fr mu, FrVec l,
+                FrVec n, ByteStream* rd) {
+  WnlaResult res;
+  for (;;) {
+    Fr roinv = fr_inv(ro);
+    if (l.size() + n.size() < 6) {
+      Fr v = add(vectorMulPP(c, l), weightVectorMul(n, n, mu));
+      Point Cc = scalarMult(g, v);
+      Cc = pointAdd(Cc, msmStrided(ctx, {{&H, 0, 1, H.n, l}, {&G, 0, 1, G.n, n}}));
+      res.l = l;
+      res.n = n;
+      res.verified = pointEq(Cc, C);
+      return res;
+    }
+    Fr y = valuesPP(rd, 1)[0];
+    FrVec c0, c1, l0, l1, n0, n1;
+    reduceVector(c, c0, c1);
+    reduceVector(l, l0, l1);
+    reduceVector(n, n0, n1);
+    size_t g0n = (G.n + 1) / 2, g1n = G.n / 2, h0n = (H.n + 1) / 2, h1n = H.n / 2;
+    FrVec l_ = vectorAddPP(l0, vectorMulOnScalar(l1, y));
+    FrVec n_ = vectorAddPP(vectorMulOnScalar(n0, roinv), vectorMulOnScalar(n1, y));
+    Fr mu2 = mul(mu, mu);
+    Fr vx = add(mul(weightVectorMul(n0, n1, mu2), mul(fr_from_u64(2), roinv)), add(vectorMulPP(c0, l1), vectorMulPP(c1, l0)));
+    Fr vr = add(weightVectorMul(n1, n1, mu2), vectorMulPP(c1, l1));
+    Point X = pointAdd(scalarMult(g, vx), msmStrided(ctx, {{&H, 0, 2, h0n, l1},
+                                                            {&H, 1, 2, h1n, l0},
+                                                            {&G, 0, 2, g0n, vectorMulOnScalar(n1, ro)},
+                                                            {&G, 1, 2, g1n, vectorMulOnScalar(n0, roinv)}}));
+    Point R = pointAdd(scalarMult(g, vr), msmStrided(ctx, {{&H, 1, 2, h1n, l1}, {&G, 1, 2, g1n, n1}}));
+    res.X.push_back(X);
+    res.R.push_back(R);
+    // H_ = H0 (+) y*H1 ; G_ = ro*G0 (+) y*G1   (docs_test.go:1325-1326), ragged folds on device
+    uint8_t oneb[32], yb[32], rob[32];
+    fr_to_be(oneb, kFrOne);
+    fr_to_be(yb, y);
+    fr_to_be(rob, ro);
+    bn256_bases *hn = nullptr, *gn = nullptr;
+    chk(bn256_fold2(ctx, H.h, 0, h0n, H.h, H.n > 1 ? 1 : 0, h1n, 2, oneb, yb, &hn));
+    DevPoints Hn(ctx, hn);
+    chk(bn256_fold2(ctx, G.h, 0, g0n, G.h, G.n > 1 ? 1 : 0, g1n, 2, rob, yb, &gn));
+    DevPoints Gn(ctx, gn);
+    FrVec c_ = vectorAddPP(c0, vectorMulOnScalar(c1, y));
+    Point C_ = pointAdd(C, scalarMult(X, y));
+    C_ = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
+    G = std::move(Gn);
+    H = std::move(Hn);
+    c = c_;
+    C = C_;
+    ro = mu;
+    mu = mu2;
+    l = l_;
+    n = n_;
+  }
+}
+
 thread_local std::string g_err;
 
 }  // namespace
@@ -725,6 +855,91 @@ extern "C" int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, 
     std::string e = innerArgVerify(ctx, n, std::move(G), std::move(H), U, P, ip);
     g_err = e;
     return e.empty() ? 0 : BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}
+
+// TestWNLA, go/bppp/docs_test.go:1242-1267, with the reader injected: g, G[nn], H[nl] from
+// RandomG1, c = values(nl), ro = values(1)[0], mu = ro^2, C = v*g + <H,l> + <G,n>.
+// out: C | u32 rounds | (X, R) per round | u32 |l| | l... | u32 |n| | n...
+extern "C" int bp_wnla_det(bn256_ctx* ctx, uint64_t seed, int nl, int nn, const uint8_t* l_be, const uint8_t* n_be,
+                           uint8_t* out, size_t cap, size_t* out_len) {
+  try {
+    if (!ctx || !l_be || !n_be || !out || !out_len || nl < 1 || nn < 1) return BN256_EINVAL;
+    ByteStream rd{seed};
+    Point g = points(ctx, rd, 1).at(0);
+    DevPoints G = points(ctx, rd, nn), H = points(ctx, rd, nl);
+    FrVec c = valuesPP(&rd, nl);
+    Fr ro = valuesPP(&rd, 1)[0], mu = mul(ro, ro);
+    FrVec l(nl), n(nn);
+    for (int i = 0; i < nl; i++) l[i] = fr_from_be(l_be + 32 * i);
+    for (int i = 0; i < nn; i++) n[i] = fr_from_be(n_be + 32 * i);
+    Fr v = add(vectorMulPP(c, l), weightVectorMul(n, n, mu));
+    Point C = pointAdd(scalarMult(g, v), msmStrided(ctx, {{&H, 0, 1, H.n, l}, {&G, 0, 1, G.n, n}}));
+    WnlaResult r = wnla(ctx, g, std::move(G), std::move(H), c, C, ro, mu, l, n, &rd);
+    std::vector<uint8_t> o(C.b, C.b + 64);
+    auto u32be = [&](uint32_t k) {
+      o.push_back((uint8_t)(k >> 24)); o.push_back((uint8_t)(k >> 16)); o.push_back((uint8_t)(k >> 8)); o.push_back((uint8_t)k);
+    };
+    u32be((uint32_t)r.X.size());
+    for (size_t i = 0; i < r.X.size(); i++) {
+      o.insert(o.end(), r.X[i].b, r.X[i].b + 64);
+      o.insert(o.end(), r.R[i].b, r.R[i].b + 64);
+    }
+    for (const FrVec* vv : {&r.l, &r.n}) {
+      u32be((uint32_t)vv->size());
+      for (const Fr& x : *vv) {
+        uint8_t b[32];
+        fr_to_be(b, x);
+        o.insert(o.end(), b, b + 32);
+      }
+    }
+    *out_len = o.size();
+    if (o.size() > cap) return BN256_ELENGTH;
+    memcpy(out, o.data(), o.size());
+    g_err = r.verified ? "" : "Failed to verify!";
+    return r.verified ? 0 : BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}
+
+// BASELINE.json configs[3] shape: WNLA over commitment vectors of length nl / nn (e.g. 2^20) with
+// synthetic generators (bn256_random_bases) and scalars; every X / R commitment and every
+// generator fold runs on the device.  Reports wall milliseconds and the number of rounds; the
+// argument's own final check (docs_test.go:1273-1288) is the correctness criterion.
+extern "C" int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_t nn, double* ms_setup, double* ms_run,
+                                 int* rounds) {
+  try {
+    if (!ctx || nl < 1 || nn < 1) return BN256_EINVAL;
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    bn256_bases *gh = nullptr, *hh = nullptr, *g1 = nullptr;
+    chk(bn256_random_bases(ctx, seed, 0, nn, 0, &gh));
+    DevPoints G(ctx, gh);
+    chk(bn256_random_bases(ctx, seed + 1, 0, nl, 0, &hh));
+    DevPoints H(ctx, hh);
+    chk(bn256_random_bases(ctx, seed + 2, 0, 1, 0, &g1));
+    DevPoints gdev(ctx, g1);
+    Point g = gdev.at(0);
+    ByteStream rd{seed};
+    FrVec c = valuesPP(nullptr, (int)nl), l(nl), n(nn);
+    for (size_t i = 0; i < nl; i++) l[i] = rd.randInt();
+    for (size_t i = 0; i < nn; i++) n[i] = rd.randInt();
+    Fr ro = fr_from_u64(2), mu = mul(ro, ro);
+    Fr v = add(vectorMulPP(c, l), weightVectorMul(n, n, mu));
+    Point C = pointAdd(scalarMult(g, v), msmStrided(ctx, {{&H, 0, 1, H.n, l}, {&G, 0, 1, G.n, n}}));
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    WnlaResult r = wnla(ctx, g, std::move(G), std::move(H), c, C, ro, mu, l, n, nullptr);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    if (ms_setup) *ms_setup = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    if (ms_run) *ms_run = (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6;
+    if (rounds) *rounds = (int)r.X.size();
+    g_err = r.verified ? "" : "Failed to verify!";
+    return r.verified ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
     return BP_EFAIL;

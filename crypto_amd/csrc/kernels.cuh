@@ -120,7 +120,7 @@ __device__ __forceinline__ void recode_digit(const u32 k[8], bool neg, u32 w, u3
 
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 nb,
-                                                    u32 precomp, u32 base_off, u32 level_stride, u32 tile_len,
+                                                    u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride, u32 tile_len,
                                                     u32* __restrict__ hist, const u32* __restrict__ offsets,
                                                     u32* __restrict__ sval) {
   extern __shared__ u32 lds[];
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
         atomicAdd(&lds[mag - 1], 1u);
       } else {
         u32 pos = atomicAdd(&lds[mag - 1], 1u);
-        u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i;
+        u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i * pt_stride;
         sval[pos] = (tidx << 1) | sign;
       }
     }
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_tile_scan(u32* __restrict__ hist, u32 n
 //   SCATTER = false: rank[w*n+i] = atomicAdd(count[key], 1);  SCATTER = true: sval[offsets[key] + rank] = entry
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W,
-                                                u32 nb, u32 precomp, u32 base_off, u32 level_stride,
+                                                u32 nb, u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride,
                                                 u32* __restrict__ counts, u32* __restrict__ rank,
                                                 const u32* __restrict__ offsets, u32* __restrict__ sval) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scal
       rank[(size_t)w * n + i] = atomicAdd(&counts[key], 1u);
     } else {
       u32 pos = offsets[key] + rank[(size_t)w * n + i];
-      u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i;
+      u32 tidx = (precomp ? w * level_stride : 0u) + base_off + i * pt_stride;
       sval[pos] = (tidx << 1) | sign;
     }
   }
@@ -582,19 +582,22 @@ __global__ void __launch_bounds__(256) k_add_points(const aff_mem* __restrict__ 
 __global__ void __launch_bounds__(256) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
                                                      u32 stride, const uint8_t* __restrict__ s_lo_be,
                                                      const uint8_t* __restrict__ s_hi_be, aff_mem* __restrict__ out,
-                                                     u32 n) {
+                                                     u32 n_lo, u32 n_hi) {
+  // out has max(n_lo, n_hi) entries; a missing side counts as infinity (vectorPointsAdd padding,
+  // go/bppp/util.go:279-293)
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 n = n_lo > n_hi ? n_lo : n_hi;
   if (i >= n) return;
   fe x, y;
   xyzz a, b, r;
   xyzz_set_inf(a);
   xyzz_set_inf(b);
   u32 k[8];
-  if (aff_load(x, y, &lo[(size_t)i * stride], false)) {
+  if (i < n_lo && aff_load(x, y, &lo[(size_t)i * stride], false)) {
     scalar_load_be(k, s_lo_be);
     g1_scalar_mul(a, x, y, k);
   }
-  if (aff_load(x, y, &hi[(size_t)i * stride], false)) {
+  if (i < n_hi && aff_load(x, y, &hi[(size_t)i * stride], false)) {
     scalar_load_be(k, s_hi_be);
     g1_scalar_mul(b, x, y, k);
   }

@@ -114,15 +114,17 @@ class Engine:
         self._chk(self.lib.bn256_msm_dev(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), out))
         return out.raw
 
-    def msm_multi(self, segments: Sequence[tuple[Bases, int, Sequence[int]]]) -> bytes:
+    def msm_multi(self, segments: Sequence[tuple]) -> bytes:
+        """segments: (bases, off, scalars) or (bases, off, scalars, stride)."""
         k = len(segments)
         hs = (C.c_void_p * max(k, 1))(*[s[0].h for s in segments])
         offs = (C.c_size_t * max(k, 1))(*[s[1] for s in segments])
+        strides = (C.c_size_t * max(k, 1))(*[(s[3] if len(s) > 3 else 1) for s in segments])
         raws = [scalars_to_bytes(s[2]) for s in segments]
         ns = (C.c_size_t * max(k, 1))(*[len(r) // 32 for r in raws])
         ptrs = (C.c_char_p * max(k, 1))(*raws)
         out = C.create_string_buffer(64)
-        self._chk(self.lib.bn256_msm_multi(self.ctx, k, hs, offs, ns, ptrs, out))
+        self._chk(self.lib.bn256_msm_multi_strided(self.ctx, k, hs, offs, strides, ns, ptrs, out))
         return out.raw
 
     # reference-named helpers (go/bp/util.go) -----------------------------------------
@@ -167,6 +169,14 @@ class Engine:
         h = C.c_void_p()
         self._chk(self.lib.bn256_fold(self.ctx, lo.h, lo_off, hi.h, hi_off, stride, n,
                                       int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"), C.byref(h)))
+        return Bases(self, h)
+
+    def fold2(self, lo: Bases, lo_off: int, n_lo: int, hi: Bases, hi_off: int, n_hi: int, s_lo: int, s_hi: int,
+              stride: int = 1) -> Bases:
+        """Ragged fold: a missing side counts as infinity (vectorPointsAdd, go/bppp/util.go:279-293)."""
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_fold2(self.ctx, lo.h, lo_off, n_lo, hi.h, hi_off, n_hi, stride,
+                                       int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"), C.byref(h)))
         return Bases(self, h)
 
     def g1_sum(self, pts: Sequence[bytes]) -> bytes:

@@ -68,6 +68,13 @@ int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, co
 int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
                     const uint8_t* const* scalars_be, uint8_t out_xy_be[64]);
 
+/* As bn256_msm_multi with a point stride per segment: segment j sums scalars[j][i] *
+ * bases[j][off[j] + i*stride[j]].  stride 2 addresses the even / odd halves that the WNLA round
+ * takes with reducePoints (go/bppp/util.go:213-226, go/bppp/docs_test.go:1297-1320). */
+int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                            const size_t* stride, const size_t* n, const uint8_t* const* scalars_be,
+                            uint8_t out_xy_be[64]);
+
 /* out_i = s_i * in[off+i] (broadcast = 0, go/bp/main.go:156-159) or s * in[off+i]
  * (broadcast = 1, vectorPointMulOnScalar, go/bp/util.go:177-183).  Result stays on device. */
 int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
@@ -83,6 +90,12 @@ int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn2
 int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256_bases* hi, size_t hi_off,
                size_t stride, size_t n, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
                bn256_bases** out);
+
+/* Ragged form of bn256_fold: out has max(n_lo, n_hi) points and a missing side counts as
+ * infinity -- vectorPointsAdd's padding (go/bppp/util.go:279-293) for odd-length WNLA rounds. */
+int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                bn256_bases** out);
 
 /* Marshal() of n points of a handle into host memory. */
 int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be);

@@ -34,6 +34,17 @@ int bp_verify_det(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t* proof, si
 /* InnerArgumentPublic.Prove + Verify round trip -- go/bp/main.go:263-377 (TestInnerArgumentProof shape). */
 int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t* a_be, const uint8_t* b_be, int tamper);
 
+/* TestWNLA (go/bppp/docs_test.go:1242-1267) + wnla (:1269-1338) with the reader injected.
+ * out: C | u32 BE rounds | (X, R) per round | u32 |l| | l.. | u32 |n| | n..  (opened vectors).
+ * 0 = the argument's final check passed, BP_EVERIFY = "Failed to verify!". */
+int bp_wnla_det(bn256_ctx* ctx, uint64_t seed, int nl, int nn, const uint8_t* l_be, const uint8_t* n_be,
+                uint8_t* out, size_t cap, size_t* out_len);
+
+/* BASELINE.json configs[3] shape: the same argument over synthetic commitment vectors of length
+ * nl / nn (e.g. 2^20); reports wall ms for set-up and for the rounds, and the round count. */
+int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_t nn, double* ms_setup, double* ms_run,
+                      int* rounds);
+
 /* hash()'s digest function: legacy Keccak-256 -- go/bp/util.go:232. */
 int bp_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]);
 

@@ -713,3 +713,83 @@ def bp_verify(pub: BulletProofPublic, pr) -> str | None:
     Pm = add(Pm, mul(pr["tx"], pub.inner.U))
     return inner_arg_verify(InnerArgumentPublic(n, IG, h1, pub.inner.U), Pm,
                             pr["L"], pr["R"], pr["a"], pr["b"])
+
+
+# --------------------------------------------------------------------------------------
+# Bulletproofs++ weighted-norm-linear argument, go/bppp/docs_test.go:1242-1338.
+# --------------------------------------------------------------------------------------
+def values_bppp(reader: ByteStream, n: int):
+    """go/bppp/util.go:11-25: rand.Int is drawn and discarded, the value is the constant 2."""
+    out = []
+    for _ in range(n):
+        rand_int(reader)
+        out.append(2)
+    return out
+
+
+def reduce_points(v):
+    """go/bppp/util.go:213-226."""
+    return list(v[0::2]), list(v[1::2])
+
+
+def vector_point_mul_on_scalar_bppp(g, a):
+    return [mul(a % N, p) for p in g]
+
+
+def wnla(g, G, H, c, C, ro, mu, l, n, reader, rounds=None):
+    """go/bppp/docs_test.go:1269-1338.  Returns (verified, rounds) with rounds = [(X, R), ...];
+    raises ValueError("Failed to verify!") where the reference panics."""
+    rounds = [] if rounds is None else rounds
+    roinv = finv(ro)
+    if len(l) + len(n) < 6:
+        v = fadd(vector_mul_bppp(c, l), weight_vector_mul(n, n, mu))
+        Cc = mul(v, g)
+        Cc = add(Cc, vector_point_scalar_mul_bppp(H, l))
+        Cc = add(Cc, vector_point_scalar_mul_bppp(G, n))
+        if marshal(Cc) != marshal(C):
+            raise ValueError("Failed to verify!")
+        return True, rounds, l, n
+    y = values_bppp(reader, 1)[0]
+    c0, c1 = reduce_vector(c)
+    l0, l1 = reduce_vector(l)
+    n0, n1 = reduce_vector(n)
+    G0, G1 = reduce_points(G)
+    H0, H1 = reduce_points(H)
+    l_ = vector_add_bppp(l0, vector_mul_on_scalar(l1, y))
+    n_ = vector_add_bppp(vector_mul_on_scalar(n0, roinv), vector_mul_on_scalar(n1, y))
+    mu2 = fmul(mu, mu)
+    vx = fadd(fmul(weight_vector_mul(n0, n1, mu2), fmul(2, roinv)),
+              fadd(vector_mul_bppp(c0, l1), vector_mul_bppp(c1, l0)))
+    vr = fadd(weight_vector_mul(n1, n1, mu2), vector_mul_bppp(c1, l1))
+    X = mul(vx, g)
+    X = add(X, vector_point_scalar_mul_bppp(H0, l1))
+    X = add(X, vector_point_scalar_mul_bppp(H1, l0))
+    X = add(X, vector_point_scalar_mul_bppp(G0, vector_mul_on_scalar(n1, ro)))
+    X = add(X, vector_point_scalar_mul_bppp(G1, vector_mul_on_scalar(n0, roinv)))
+    R = mul(vr, g)
+    R = add(R, vector_point_scalar_mul_bppp(H1, l1))
+    R = add(R, vector_point_scalar_mul_bppp(G1, n1))
+    rounds.append((X, R))
+    H_ = vector_points_add_bppp(H0, vector_point_mul_on_scalar_bppp(H1, y))
+    G_ = vector_points_add_bppp(vector_point_mul_on_scalar_bppp(G0, ro), vector_point_mul_on_scalar_bppp(G1, y))
+    c_ = vector_add_bppp(c0, vector_mul_on_scalar(c1, y))
+    C_ = add(C, mul(y, X))
+    C_ = add(C_, mul(fsub(fmul(y, y), 1), R))
+    return wnla(g, G_, H_, c_, C_, mu, mu2, l_, n_, reader, rounds)
+
+
+def wnla_setup_and_run(seed: int, l, n):
+    """TestWNLA, go/bppp/docs_test.go:1242-1267, with the reader injected."""
+    rd = ByteStream(seed)
+    g = points(rd, 1)[0]
+    G = points(rd, len(n))
+    H = points(rd, len(l))
+    c = values_bppp(rd, len(l))
+    ro = values_bppp(rd, 1)[0]
+    mu = fmul(ro, ro)
+    v = fadd(vector_mul_bppp(c, l), weight_vector_mul(n, n, mu))
+    C = mul(v, g)
+    C = add(C, vector_point_scalar_mul_bppp(H, l))
+    C = add(C, vector_point_scalar_mul_bppp(G, n))
+    ok, rounds, lf, nf = wnla(g, G, H, c, C, ro, mu, list(l), list(n), rd)
+    return dict(C=C, rounds=rounds, l=lf, n=nf, ok=ok)

@@ -70,3 +70,58 @@ def test_inner_product_argument(bp):
     a = [rnd.randrange(N_ORDER) for _ in range(32)]
     b = [rnd.randrange(N_ORDER) for _ in range(32)]
     assert bp.inner_product_roundtrip(32, 99, a, b) is None
+
+
+# ------------------------------------------------------------------ go/bppp: WNLA
+@pytest.fixture(scope="module")
+def wnla(eng):
+    from crypto_amd.bp import WNLA
+    return WNLA(eng)
+
+
+@pytest.mark.parametrize("l,n", [
+    ([4, 5, 10, 1, 99, 35, 1, 15], [1, 3, 42, 14]),          # TestWNLA, go/bppp/docs_test.go:1257-1258
+    ([4, 5, 10, 1, 99, 35, 1], [1, 3, 42, 14, 9]),           # odd lengths: pad / truncate paths
+    ([7, 8], [1, 2, 3]),                                     # opened immediately (len(l)+len(n) < 6)
+    (list(range(1, 34)), list(range(100, 117))),             # 33 / 17
+])
+def test_wnla_matches_oracle(wnla, l, n):
+    import bn256_ref as ref
+    seed = 0x77AA + len(l)
+    want = ref.wnla_setup_and_run(seed, l, n)
+    got = wnla.run(seed, l, n)
+    assert got["ok"] and want["ok"]
+    assert got["C"] == ref.marshal(want["C"]).hex()
+    assert got["rounds"] == [(ref.marshal(x).hex(), ref.marshal(r).hex()) for x, r in want["rounds"]]
+    assert got["l"] == want["l"] and got["n"] == want["n"]
+
+
+def test_wnla_2_16_commitment_vectors(wnla):
+    """Scaled-down BASELINE.json configs[3]: every X / R commitment and generator fold on the
+    device; the argument's own final check is the criterion (size-independent property)."""
+    r = wnla.synthetic(0xABCD, 1 << 16, 1 << 15)
+    assert r["ok"] and r["rounds"] >= 14
+
+
+def test_strided_msm_and_ragged_fold(eng, orc):
+    n = 37
+    braw = orc.synth_bases(0x51, n)
+    sraw = orc.synth_scalars(0x52, n)
+    sc = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(n)]
+    h = eng.upload(braw)
+    ev = b"".join(braw[64 * i:64 * i + 64] for i in range(0, n, 2))
+    od = b"".join(braw[64 * i:64 * i + 64] for i in range(1, n, 2))
+    ne, no = (n + 1) // 2, n // 2
+    got = eng.msm_multi([(h, 0, sc[:ne], 2), (h, 1, sc[ne:ne + no], 2)])
+    want = orc.add(orc.msm(ev, sraw[:32 * ne]), orc.msm(od, sraw[32 * ne:32 * (ne + no)]))
+    assert got == want
+    import crypto_amd
+    with pytest.raises(crypto_amd.BN256Error):
+        eng.msm_multi([(h, 1, sc[:no + 1], 2)])              # one past the end of the odd view
+    out = eng.fold2(h, 0, ne, h, 1, no, 3, 5, stride=2).download()
+    assert len(out) == ne
+    for i in range(ne):
+        w = orc.mul(braw[128 * i:128 * i + 64], 3)
+        if i < no:
+            w = orc.add(w, orc.mul(braw[128 * i + 64:128 * i + 128], 5))
+        assert out[i] == w
