@@ -113,6 +113,14 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
+        traffic = None
+        try:  # HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (2^20, c=16 only)
+            if args.log2n == 20 and not args.no_precompute and not args.window_bits:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_2p20.json")) as f:
+                    pmc = json.load(f)["k_accumulate"]
+                traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
+        except Exception:
+            traffic = None
         phase = [p / steps for p in phase]
         acc_s = phase[3] * 1e-3
         achieved = n * IMAD_PER_POINT / acc_s if acc_s > 0 else 0.0
@@ -147,7 +155,7 @@ def main():
                 "peak": IMAD_PEAK,
                 "unit": "IMAD/s",
                 "frac": achieved / IMAD_PEAK,
-                "traffic": None,
+                "traffic": traffic,
                 "whole_msm_frac": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK,
             },
         }
