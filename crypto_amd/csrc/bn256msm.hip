@@ -349,14 +349,14 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
                      (const u32*)offsets, (u32)nbt, K, buckets, partials);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
-  hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
+  hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
                      (const xyzz_mem*)partials, heavy_count, heavy_list);
   hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
                      (const u32*)heavy_count, (const u32*)heavy_list);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
-    hipLaunchKernelGGL(k_fold, dim3(nblocks(threads, 64)), dim3(64), 0, s, buckets, nsets, nb, l);
+    hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, buckets, nsets, nb, l);
   }
   hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)buckets, nsets, nb, q,
                      d_pack);

@@ -234,6 +234,67 @@ __device__ __forceinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) 
   r.zzz = zzz3;
 }
 
+// ------------------------------------------------------------------ quad-cooperative addition
+// The bucket-reduction tail is a chain of dependent XYZZ additions executed by very few
+// waves, and one wave alone issues a VALU instruction only every ~9.5 clk, so an addition is
+// pure latency (14 dependent multiplies).  Here the four lanes of a quad hold the same
+// operands and each lane runs one multiply of a four-wide stage; results are exchanged with
+// DPP quad_perm broadcasts (no LDS).  14 sequential multiplies become 4.
+template <int K>
+__device__ __forceinline__ fe fe_quad_bcast(const fe& v) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = __builtin_amdgcn_update_dpp(0, v.v[i], K * 0x55, 0xf, 0xf, true);
+  return r;
+}
+__device__ __forceinline__ fe fe_sel4(u32 role, const fe& a0, const fe& a1, const fe& a2, const fe& a3) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    i32 lo = (role & 1u) ? a1.v[i] : a0.v[i];
+    i32 hi = (role & 1u) ? a3.v[i] : a2.v[i];
+    r.v[i] = (role & 2u) ? hi : lo;
+  }
+  return r;
+}
+// r = a + b.  Must be called by all four lanes of a quad with identical a and b; every lane
+// returns the full result.  role = lane & 3.
+__device__ __forceinline__ void xyzz_add_quad(xyzz& r, const xyzz& a, const xyzz& b, u32 role) {
+  if (xyzz_is_inf(a)) {
+    r = b;
+    return;
+  }
+  if (xyzz_is_inf(b)) {
+    r = a;
+    return;
+  }
+  fe m1 = fe_mul(fe_sel4(role, a.x, b.x, a.y, b.y), fe_sel4(role, b.zz, a.zz, b.zzz, a.zzz));
+  fe u1 = fe_quad_bcast<0>(m1), u2 = fe_quad_bcast<1>(m1), s1 = fe_quad_bcast<2>(m1), s2 = fe_quad_bcast<3>(m1);
+  fe h = fe_sub(u2, u1);
+  fe rr = fe_sub(s2, s1);
+  fe m2 = fe_mul(fe_sel4(role, a.zz, a.zzz, h, rr), fe_sel4(role, b.zz, b.zzz, h, rr));
+  fe zz12 = fe_quad_bcast<0>(m2), zzz12 = fe_quad_bcast<1>(m2), pp = fe_quad_bcast<2>(m2), rr2 = fe_quad_bcast<3>(m2);
+  if (fe_maybe_zero_sq(pp)) {
+    if (fe_is_zero_mod_p(h)) {  // P == +-Q: rare, every lane takes the serial path
+      if (fe_is_zero_mod_p(rr)) {
+        r = xyzz_dbl_outofline(a);
+      } else {
+        xyzz_set_inf(r);
+      }
+      return;
+    }
+  }
+  fe m3 = fe_mul(fe_sel4(role, h, u1, zz12, h), pp);
+  fe ppp = fe_quad_bcast<0>(m3), q = fe_quad_bcast<1>(m3), zz3 = fe_quad_bcast<2>(m3);
+  fe x3 = fe_norm(fe_sub(fe_sub(fe_sub(rr2, ppp), q), q));
+  fe m4 = fe_mul(fe_sel4(role, rr, s1, zzz12, rr), fe_sel4(role, fe_sub(q, x3), ppp, ppp, ppp));
+  fe t1 = fe_quad_bcast<0>(m4), t2 = fe_quad_bcast<1>(m4), zzz3 = fe_quad_bcast<2>(m4);
+  r.x = x3;
+  r.y = fe_norm(fe_sub(t1, t2));
+  r.zz = zz3;
+  r.zzz = zzz3;
+}
+
 // Normalise to affine; outputs canonical Montgomery limbs.  Returns false for infinity.
 __device__ __forceinline__ bool xyzz_to_affine(fe& x, fe& y, const xyzz& a) {
   if (xyzz_is_inf(a)) return false;

@@ -341,29 +341,31 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
                                                    xyzz_mem* __restrict__ buckets,
                                                    const xyzz_mem* __restrict__ partials,
                                                    u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
-  u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  // one quad (4 lanes) per bucket: the serial chain of additions runs quad-cooperatively
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 b = tid >> 2, role = tid & 3u;
   if (b >= nbt) return;
   u32 lo = offsets[b], hi = offsets[b + 1];
   xyzz acc;
   if (lo == hi) {
     xyzz_set_inf(acc);
-    xyzz_store(&buckets[b], acc);
+    if (role == 0) xyzz_store(&buckets[b], acc);
     return;
   }
   u32 t0 = lo / K, t1 = (hi - 1) / K;
   if (t0 == t1) return;
   if (t1 - t0 + 1 > FIX_CAP) {
-    heavy_list[atomicAdd(heavy_count, 1u)] = b;
+    if (role == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
     return;
   }
   xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
   for (u32 t = t0 + 1; t <= t1; t++) {
     xyzz p, r;
     xyzz_load(p, &partials[2 * (size_t)t]);
-    xyzz_add(r, acc, p);
+    xyzz_add_quad(r, acc, p, role);
     acc = r;
   }
-  xyzz_store(&buckets[b], acc);
+  if (role == 0) xyzz_store(&buckets[b], acc);
 }
 
 // One workgroup per heavy bucket: the threads split the partials (strided), then a
@@ -409,9 +411,12 @@ __global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, 
 // Level l (width w = nb >> l) folds the main row [0,w) and the l rows at bases nb>>j
 // (j = 1..l) in half: B[base+i] += B[base+i+w/2].  After c-1 levels T = B[0], G_k = B[2^k].
 __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  // one quad per output element (quad-cooperative addition, see g1.cuh)
   u32 half = (nb >> level) >> 1;
   u32 rows = level + 1;
-  u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  u64 tid = gid >> 2;
+  u32 role = (u32)gid & 3u;
   u64 per_set = (u64)rows * half;
   if (tid >= per_set * nsets) return;
   u32 set = (u32)(tid / per_set);
@@ -422,8 +427,8 @@ __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32
   xyzz a, b, r;
   xyzz_load(a, p);
   xyzz_load(b, p + half);
-  xyzz_add(r, a, b);
-  xyzz_store(p, r);
+  xyzz_add_quad(r, a, b, role);
+  if (role == 0) xyzz_store(p, r);
 }
 
 // Canonical, non-Montgomery X,Y,ZZ,ZZZ (8 x u32 LE each) of T and G_k for the host tail.
