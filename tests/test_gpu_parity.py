@@ -60,7 +60,7 @@ def test_random_scalars_match_oracle(eng, orc, golden):
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c[1] <= 1024], ids=lambda c: c[0])
-@pytest.mark.parametrize("mode", ["plain", "precomp", "c4", "c7_k3", "c13"])
+@pytest.mark.parametrize("mode", ["plain", "precomp", "c4", "c7_k3", "c13", "c18_fallback", "c18_precomp"])
 def test_msm_cases(eng, orc, golden, case, mode):
     import crypto_amd
     want = bytes.fromhex(next(m for m in golden["msm"] if m["name"] == case[0])["result"])
@@ -72,7 +72,9 @@ def test_msm_cases(eng, orc, golden, case, mode):
             eng.set_tuning(7, 3)
         elif mode == "c13":
             eng.set_tuning(13, 5)
-        h = eng.upload(bases, crypto_amd.PRECOMPUTE if mode == "precomp" else 0)
+        elif mode.startswith("c18"):      # bucket array too large for LDS: global-atomic sort fallback
+            eng.set_tuning(18, 0)
+        h = eng.upload(bases, crypto_amd.PRECOMPUTE if "precomp" in mode else 0)
         got = eng.msm(h, scalars)
         h.free()
     finally:
@@ -223,3 +225,24 @@ def test_skewed_scalar_distributions_65536(eng, orc, mode):
     assert eng.msm(h, sraw) == orc.msm(braw, sraw, mt=True)
     sraw = ((1 << 240) + 3).to_bytes(32, "big") * n
     assert eng.msm(h, sraw) == orc.msm(braw, sraw, mt=True)
+
+
+def test_two_contexts_are_independent(orc):
+    """Distinct contexts share nothing (include/bn256msm.h conventions)."""
+    import crypto_amd
+    e1, e2 = crypto_amd.Engine(0), crypto_amd.Engine(0)
+    try:
+        n = 300
+        braw = orc.synth_bases(0xE1, n)
+        sraw = orc.synth_scalars(0xE2, n)
+        h1, h2 = e1.upload(braw), e2.upload(braw[:64 * 100], crypto_amd.PRECOMPUTE)
+        want1 = orc.msm(braw, sraw)
+        want2 = orc.msm(braw[:64 * 100], sraw[:32 * 100])
+        for _ in range(3):
+            assert e1.msm(h1, sraw) == want1
+            assert e2.msm(h2, sraw[:32 * 100]) == want2
+        h1.free()
+        h2.free()
+    finally:
+        e1.close()
+        e2.close()
