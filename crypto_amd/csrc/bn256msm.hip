@@ -147,12 +147,12 @@ static int ilog2_floor(size_t n) {
 // window width: fixed-base tables have a single bucket set, so wide windows are cheap
 static int pick_c(const bn256_ctx* ctx, size_t n, bool precomp) {
   if (ctx->tune_c) return ctx->tune_c;
+  // Measured on MI355X (tools/perf_msm.py sweeps, DESIGN.md "window size"): c = 16 keeps the
+  // whole 2^15-bucket histogram in LDS and leaves a full-width top window (255 = 15*16 + 15);
+  // the smaller choices are the ones whose top window is not a few-bucket hot spot.
   int lg = ilog2_floor(n ? n : 1);
-  int c = precomp ? lg - 4 : lg - 4;
-  if (!precomp && c > 16) c = 16;
-  if (c > 20) c = 20;
-  if (c < 3) c = 3;
-  return c;
+  if (precomp) return lg >= 13 ? 16 : (lg >= 9 ? 13 : 10);
+  return lg >= 17 ? 16 : (lg >= 15 ? 10 : 8);
 }
 static inline int windows_for(int c) { return 255 / c + 1; }
 

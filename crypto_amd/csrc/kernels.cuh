@@ -103,11 +103,6 @@ __device__ __forceinline__ u32 scalar_bits(const u32 k[8], u32 bit, u32 width) {
 //   k_scan1/2/3    : exclusive scan of totals -> offsets[bucket]  (offsets[nbt] = #entries)
 //   k_tile_scatter : LDS cursors = offsets + tile prefix; pos = ds_add_rtn(cursor[key], 1);
 //                    sval[pos] = entry.  No global atomics anywhere.
-#define RECODE_MAXW 64
-struct recoded {
-  u32 k[8];
-  bool neg;
-};
 // digit of window w (call with w = 0, 1, 2, ... in order; carry threads through)
 __device__ __forceinline__ void recode_digit(const u32 k[8], bool neg, u32 w, u32 c, u32& carry, u32& mag, u32& sign) {
   const u32 half = 1u << (c - 1);
@@ -116,6 +111,18 @@ __device__ __forceinline__ void recode_digit(const u32 k[8], bool neg, u32 w, u3
   mag = over ? ((1u << c) - raw) : raw;
   carry = over ? 1u : 0u;
   sign = (over != neg) ? 1u : 0u;
+}
+
+// carry entering window w without walking the windows below it: the window below decides unless
+// its raw value is exactly half (probability 2^-c), in which case the one below that does.
+__device__ __forceinline__ u32 recode_carry_into(const u32 k[8], u32 w, u32 c) {
+  const u32 half = 1u << (c - 1);
+  while (w > 0) {
+    u32 raw = scalar_bits(k, (w - 1) * c, c);
+    if (raw != half) return raw > half ? 1u : 0u;
+    w--;
+  }
+  return 0u;
 }
 
 template <bool SCATTER>
@@ -139,11 +146,13 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
     u32 k[8];
     scalar_load_be(k, scalars_be + (size_t)i * 32);
     bool neg = scalar_reduce_signed(k);
-    u32 carry = 0;
-    for (u32 w = 0; w < W; w++) {
+    // with a table one workgroup bins every window of its scalars; without, only window `set`
+    const u32 w_lo = precomp ? 0u : set, w_hi = precomp ? W : set + 1u;
+    u32 carry = precomp ? 0u : recode_carry_into(k, set, c);
+    for (u32 w = w_lo; w < w_hi; w++) {
       u32 mag, sign;
       recode_digit(k, neg, w, c, carry, mag, sign);
-      if (mag == 0 || (!precomp && w != set)) continue;
+      if (mag == 0) continue;
       if (!SCATTER) {
         atomicAdd(&lds[mag - 1], 1u);
       } else {
