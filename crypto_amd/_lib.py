@@ -13,6 +13,8 @@ EXPORTS = [
     "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_multi", "bn256_msm_multi_strided", "bn256_fold2", "bn256_scalar_mul_batch",
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
+    "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
+    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr",
 ]
 
 _lib = None
@@ -58,6 +60,18 @@ def load() -> C.CDLL:
     lib.bn256_bases_download.argtypes = [vp, vp, sz, sz, u8p]
     lib.bn256_random_bases.argtypes = [vp, C.c_uint64, sz, sz, i, C.POINTER(vp)]
     lib.bn256_random_scalars.argtypes = [vp, C.c_uint64, sz, sz, vp]
+    lib.bn256_fr_upload.argtypes = [vp, u8p, sz, C.POINTER(vp)]
+    lib.bn256_fr_random.argtypes = [vp, C.c_uint64, sz, sz, C.POINTER(vp)]
+    lib.bn256_fr_download.argtypes = [vp, vp, sz, sz, u8p]
+    lib.bn256_fr_len.argtypes = [vp]
+    lib.bn256_fr_len.restype = sz
+    lib.bn256_fr_device_ptr.argtypes = [vp]
+    lib.bn256_fr_device_ptr.restype = vp
+    lib.bn256_fr_free.argtypes = [vp, vp]
+    lib.bn256_fr_free.restype = None
+    lib.bn256_fr_fold.argtypes = [vp, vp, sz, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp)]
+    lib.bn256_fr_dot.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, sz, u8p, u8p]
+    lib.bn256_msm_fr.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, u8p]
     lib.bn256_g1_sum.argtypes = [u8p, sz, u8p]
     lib.bn256_ctx_set_tuning.argtypes = [vp, i, i]
     lib.bn256_last_timing.argtypes = [vp, C.POINTER(C.c_float), i]

@@ -255,7 +255,7 @@ extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t
 // Runs the device pipeline for one contiguous range with device-resident scalars and returns
 // the XYZZ sum as a host point.
 static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
-                    const uint8_t* d_scalars, hostg1::Pt* result) {
+                    const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1) {
   using namespace hostg1;
   *result = infinity();
   for (float& f : ctx->last_ms) f = 0.f;
@@ -323,14 +323,15 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
   if (use_lds) {
     hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
-                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, hist, (const u32*)nullptr,
-                       (u32*)nullptr);
+                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
+                       (const u32*)nullptr, (u32*)nullptr);
     HIPCHK(hipEventRecord(ctx->ev[1], s));
     hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
   } else {
     HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
     hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, counts, rank, (const u32*)nullptr, (u32*)nullptr);
+                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank, (const u32*)nullptr,
+                       (u32*)nullptr);
     HIPCHK(hipEventRecord(ctx->ev[1], s));
   }
   // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
@@ -340,10 +341,12 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   HIPCHK(hipEventRecord(ctx->ev[2], s));
   if (use_lds) {
     hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
-                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, hist, (const u32*)offsets, sval);
+                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
+                       (const u32*)offsets, sval);
   } else {
     hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, counts, rank, (const u32*)offsets, sval);
+                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank, (const u32*)offsets,
+                       sval);
   }
   HIPCHK(hipEventRecord(ctx->ev[3], s));
   hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
@@ -589,6 +592,181 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
     }
   }
   *out = b;
+  return BN256_OK;
+}
+
+// ---------------------------------------------------------------------------- Fr vectors
+struct bn256_frvec {
+  uint8_t* d;  // n x 32-byte big-endian scalars
+  size_t n;
+};
+
+static bn256_frvec* frvec_alloc(size_t n, int* rc) {
+  bn256_frvec* v = new (std::nothrow) bn256_frvec();
+  if (!v) {
+    *rc = BN256_ENOMEM;
+    return nullptr;
+  }
+  v->d = nullptr;
+  v->n = n;
+  hipError_t e = hipMalloc((void**)&v->d, std::max<size_t>(n, 1) * 32);
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    delete v;
+    *rc = e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
+    return nullptr;
+  }
+  *rc = BN256_OK;
+  return v;
+}
+
+extern "C" void bn256_fr_free(bn256_ctx* ctx, bn256_frvec* v) {
+  if (!v) return;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (v->d) (void)hipFree(v->d);
+  delete v;
+}
+extern "C" size_t bn256_fr_len(const bn256_frvec* v) { return v ? v->n : 0; }
+extern "C" const void* bn256_fr_device_ptr(const bn256_frvec* v) { return v ? v->d : nullptr; }
+
+extern "C" int bn256_fr_upload(bn256_ctx* ctx, const uint8_t* scalars_be, size_t n, bn256_frvec** out) {
+  if (!ctx || !out || (!scalars_be && n)) return BN256_EINVAL;
+  *out = nullptr;
+  if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  bn256_frvec* v = frvec_alloc(n, &rc);
+  if (!v) return rc;
+  if (n) {
+    hipError_t e = hipMemcpyAsync(v->d, scalars_be, n * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_fr_free(ctx, v); return BN256_EHIP; }
+  }
+  *out = v;
+  return BN256_OK;
+}
+
+extern "C" int bn256_fr_random(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, bn256_frvec** out) {
+  if (!ctx || !out) return BN256_EINVAL;
+  *out = nullptr;
+  if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  bn256_frvec* v = frvec_alloc(n, &rc);
+  if (!v) return rc;
+  rc = bn256_random_scalars(ctx, seed, first, n, v->d);
+  if (rc) { bn256_fr_free(ctx, v); return rc; }
+  *out = v;
+  return BN256_OK;
+}
+
+extern "C" int bn256_fr_download(bn256_ctx* ctx, const bn256_frvec* v, size_t off, size_t n, uint8_t* scalars_be) {
+  if (!ctx || !v || (!scalars_be && n)) return BN256_EINVAL;
+  if (off > v->n || n > v->n - off) return BN256_ELENGTH;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n) {
+    HIPCHK(hipMemcpyAsync(scalars_be, v->d + off * 32, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return BN256_OK;
+}
+
+// number of elements of the strided view v[off], v[off+stride], ... is at least n
+static int fr_range_check(const bn256_frvec* v, size_t off, size_t n, size_t stride) {
+  if (stride == 0) return BN256_EINVAL;
+  if (off > v->n) return BN256_ELENGTH;
+  if (n == 0) return BN256_OK;
+  size_t avail = v->n - off;
+  if (avail == 0 || (n - 1) > (avail - 1) / stride) return BN256_ELENGTH;
+  return BN256_OK;
+}
+static fr_arg fr_arg_from_be(const uint8_t be[32]) {
+  fr_arg a;
+  for (int i = 0; i < 8; i++) {
+    const uint8_t* p = be + 28 - 4 * i;
+    a.w[i] = ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+  }
+  return a;
+}
+// reduce an argument scalar below n (2^256 < 2n): the kernels assume canonical multipliers
+static fr_arg fr_arg_canon(fr_arg a) {
+  static const u32 nw[8] = {0x57ac7261u, 0x1a2ef45bu, 0xf82b3924u, 0x2e8d8e12u,
+                            0x6184dc21u, 0xaa6fecb8u, 0x4aa387f9u, 0x8fb501e3u};
+  u32 t[8];
+  uint64_t br = 0;
+  for (int i = 0; i < 8; i++) {
+    uint64_t d = (uint64_t)a.w[i] - nw[i] - br;
+    t[i] = (u32)d;
+    br = (d >> 32) & 1;
+  }
+  if (!br) memcpy(a.w, t, sizeof t);
+  return a;
+}
+
+extern "C" int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t n_a, const bn256_frvec* b,
+                             size_t b_off, size_t n_b, size_t stride, const uint8_t s_a_be[32],
+                             const uint8_t s_b_be[32], bn256_frvec** out) {
+  if (!ctx || !a || !b || !out || !s_a_be || !s_b_be) return BN256_EINVAL;
+  *out = nullptr;
+  int rc;
+  if ((rc = fr_range_check(a, a_off, n_a, stride)) || (rc = fr_range_check(b, b_off, n_b, stride))) return rc;
+  size_t n = std::max(n_a, n_b);
+  HIPCHK(hipSetDevice(ctx->device));
+  bn256_frvec* r = frvec_alloc(n, &rc);
+  if (!r) return rc;
+  if (n) {
+    hipLaunchKernelGGL(k_fr_fold, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)(a->d + a_off * 32), (u32)n_a, (const uint8_t*)(b->d + b_off * 32), (u32)n_b,
+                       (u32)stride, fr_arg_canon(fr_arg_from_be(s_a_be)), fr_arg_canon(fr_arg_from_be(s_b_be)), r->d,
+                       (u32)n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_fr_free(ctx, r); return BN256_EHIP; }
+  }
+  *out = r;
+  return BN256_OK;
+}
+
+extern "C" int bn256_fr_dot(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t a_stride, size_t n_a,
+                            const bn256_frvec* b, size_t b_off, size_t b_stride, size_t n_b, const uint8_t* mu_be,
+                            uint8_t out_be[32]) {
+  if (!ctx || !a || !b || !out_be) return BN256_EINVAL;
+  int rc;
+  if ((rc = fr_range_check(a, a_off, n_a, a_stride)) || (rc = fr_range_check(b, b_off, n_b, b_stride))) return rc;
+  memset(out_be, 0, 32);
+  size_t n = std::min(n_a, n_b);  // the padded tail multiplies by zero
+  if (n == 0) return BN256_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+  const u32 nthreads = (u32)((n + per - 1) / per);
+  const u32 nblk = nblocks(nthreads, 256);
+  if ((rc = ws_reserve(ctx, WS_TMP, (size_t)nblk * sizeof(fr) + 64))) return rc;
+  uint8_t* d_out = (uint8_t*)ctx->ws[WS_TMP];
+  fr* partials = (fr*)(d_out + 64);
+  fr_arg mu;
+  memset(&mu, 0, sizeof mu);
+  if (mu_be) mu = fr_arg_canon(fr_arg_from_be(mu_be));
+  hipLaunchKernelGGL(k_fr_dot, dim3(nblk), dim3(256), 0, ctx->stream, (const uint8_t*)(a->d + a_off * 32),
+                     (u32)a_stride, (u32)n_a, (const uint8_t*)(b->d + b_off * 32), (u32)b_stride, (u32)n_b, (u32)n, per,
+                     mu, (u32)(mu_be != nullptr), partials);
+  hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, ctx->stream, (const fr*)partials, nblk, d_out);
+  HIPCHK(hipMemcpyAsync(out_be, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
+                            const bn256_frvec* v, size_t v_off, size_t v_stride, uint8_t out_xy_be[64]) {
+  if (!ctx || !b || !v || !out_xy_be) return BN256_EINVAL;
+  int rc;
+  if ((rc = range_check(b, off, n, stride)) || (rc = fr_range_check(v, v_off, n, v_stride))) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  hostg1::Pt r;
+  rc = msm_core(ctx, b, off, stride, n, v->d + v_off * 32, &r, v_stride);
+  if (rc) return rc;
+  hostg1::marshal(out_xy_be, r);
   return BN256_OK;
 }
 

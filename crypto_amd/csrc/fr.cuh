@@ -1,0 +1,207 @@
+// Fr = integers mod bn256.Order on the device: the prover's scalar algebra
+// (add/sub/mul of go/bp/util.go:197-207, vectorMul / weightVectorMul / vector folds of
+// go/bp/util.go:106-163 and go/bppp/util.go:143-176,237-277).  These kernels are HBM-bound
+// (32 bytes per element, a handful of multiplications), so the representation is the plain
+// one: 8 x 32-bit words, Montgomery R = 2^256, CIOS with 64-bit accumulators.  In memory an
+// Fr vector is the reference's own scalar encoding (32-byte big-endian, canonical), which is
+// exactly what the MSM kernels consume.
+#pragma once
+#include "fe29.cuh"
+
+struct fr {
+  u32 w[8];  // little-endian words
+};
+
+__device__ __forceinline__ constexpr u32 fr_mod_word(int i) {
+  constexpr u32 n[8] = {0x57ac7261u, 0x1a2ef45bu, 0xf82b3924u, 0x2e8d8e12u,
+                        0x6184dc21u, 0xaa6fecb8u, 0x4aa387f9u, 0x8fb501e3u};
+  return n[i];
+}
+__device__ __forceinline__ constexpr u32 fr_r2_word(int i) {  // 2^512 mod n
+  constexpr u32 r2[8] = {0x2affbc35u, 0xb5f03013u, 0x0792e95du, 0x85a1f7dau,
+                         0xa6ee4895u, 0x26841e5fu, 0x765aefd5u, 0x3d8f6c73u};
+  return r2[i];
+}
+#define FR_NINV32 0x2d284e5fu  // -n^-1 mod 2^32
+
+__device__ __forceinline__ fr fr_zero() {
+  fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = 0;
+  return r;
+}
+// r = a - n if a >= n (a < 2n)
+__device__ __forceinline__ void fr_cond_sub(fr& a, u32 top_carry) {
+  u32 t[8];
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 d = (u64)a.w[i] - fr_mod_word(i) - br;
+    t[i] = (u32)d;
+    br = (d >> 32) & 1;
+  }
+  bool take = top_carry != 0 || br == 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) a.w[i] = take ? t[i] : a.w[i];
+}
+__device__ __forceinline__ fr fr_add(const fr& a, const fr& b) {
+  fr r;
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (u64)a.w[i] + b.w[i];
+    r.w[i] = (u32)c;
+    c >>= 32;
+  }
+  fr_cond_sub(r, (u32)c);
+  return r;
+}
+// Montgomery product a*b/2^256 mod n, inputs < n (or one input < 2^256 and the other < n), output < n
+__device__ __forceinline__ fr fr_mont(const fr& a, const fr& b) {
+  u32 t[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      u64 cur = (u64)a.w[j] * b.w[i] + t[j] + c;
+      t[j] = (u32)cur;
+      c = cur >> 32;
+    }
+    u64 cur = (u64)t[8] + c;
+    t[8] = (u32)cur;
+    t[9] = (u32)(cur >> 32);
+    u32 m = t[0] * FR_NINV32;
+    c = ((u64)m * fr_mod_word(0) + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      u64 cur2 = (u64)m * fr_mod_word(j) + t[j] + c;
+      t[j - 1] = (u32)cur2;
+      c = cur2 >> 32;
+    }
+    cur = (u64)t[8] + c;
+    t[7] = (u32)cur;
+    t[8] = t[9] + (u32)(cur >> 32);
+  }
+  fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = t[i];
+  fr_cond_sub(r, t[8]);
+  return r;
+}
+__device__ __forceinline__ fr fr_r2() {
+  fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = fr_r2_word(i);
+  return r;
+}
+__device__ __forceinline__ fr fr_to_mont(const fr& a) { return fr_mont(a, fr_r2()); }
+
+// 32-byte big-endian in memory (16-byte aligned) -> canonical words (reduced once: 2^256 < 2n)
+__device__ __forceinline__ fr fr_load_be(const uint8_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  fr r;
+  r.w[7] = __builtin_bswap32(a.x);
+  r.w[6] = __builtin_bswap32(a.y);
+  r.w[5] = __builtin_bswap32(a.z);
+  r.w[4] = __builtin_bswap32(a.w);
+  r.w[3] = __builtin_bswap32(b.x);
+  r.w[2] = __builtin_bswap32(b.y);
+  r.w[1] = __builtin_bswap32(b.z);
+  r.w[0] = __builtin_bswap32(b.w);
+  fr_cond_sub(r, 0);
+  return r;
+}
+__device__ __forceinline__ void fr_store_be(uint8_t* p, const fr& a) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(__builtin_bswap32(a.w[7]), __builtin_bswap32(a.w[6]), __builtin_bswap32(a.w[5]),
+                    __builtin_bswap32(a.w[4]));
+  q[1] = make_uint4(__builtin_bswap32(a.w[3]), __builtin_bswap32(a.w[2]), __builtin_bswap32(a.w[1]),
+                    __builtin_bswap32(a.w[0]));
+}
+
+struct fr_arg {  // kernel-argument form of one scalar (canonical words)
+  u32 w[8];
+};
+__device__ __forceinline__ fr fr_from_arg(const fr_arg& a) {
+  fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = a.w[i];
+  return r;
+}
+
+// out[i] = s_a * a[a_off + i*stride] + s_b * b[b_off + i*stride]; an index past n_a / n_b reads 0
+// (BP++'s pad-tolerant vectorAdd, go/bppp/util.go:245-260; IPA halves go/bp/main.go:357-358;
+// WNLA l' = l0 + y l1, n' = rho^-1 n0 + y n1, go/bppp/docs_test.go:1318-1319).
+__global__ void __launch_bounds__(256) k_fr_fold(const uint8_t* __restrict__ a, u32 n_a, const uint8_t* __restrict__ b,
+                                                 u32 n_b, u32 stride, fr_arg s_a, fr_arg s_b,
+                                                 uint8_t* __restrict__ out, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr sa = fr_to_mont(fr_from_arg(s_a)), sb = fr_to_mont(fr_from_arg(s_b));
+  fr r = fr_zero();
+  if (i < n_a) r = fr_mont(fr_load_be(a + (size_t)i * stride * 32), sa);
+  if (i < n_b) r = fr_add(r, fr_mont(fr_load_be(b + (size_t)i * stride * 32), sb));
+  fr_store_be(out + (size_t)i * 32, r);
+}
+
+// partials[block] = sum_i a_i * b_i * (weighted ? mu^(i+1) : 1) over the block's share of
+// [0, n): vectorMul (go/bp/util.go:132-142, go/bppp/util.go:143-157) and weightVectorMul
+// (go/bppp/util.go:159-176).  Thread t owns `per` consecutive indices.
+__global__ void __launch_bounds__(256) k_fr_dot(const uint8_t* __restrict__ a, u32 a_stride, u32 n_a,
+                                                const uint8_t* __restrict__ b, u32 b_stride, u32 n_b, u32 n, u32 per,
+                                                fr_arg mu_arg, u32 weighted, fr* __restrict__ partials) {
+  __shared__ fr lds[256];
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  u64 lo64 = (u64)t * per;
+  fr acc = fr_zero();
+  if (lo64 < n) {
+    u32 lo = (u32)lo64;
+    u32 hi = (n - lo > per) ? lo + per : n;
+    u32 lim = n_a < n_b ? n_a : n_b;  // beyond the shorter vector the padded product is 0
+    if (hi > lim) hi = lim;
+    fr mu = fr_to_mont(fr_from_arg(mu_arg)), w = fr_zero();
+    if (weighted && lo < hi) {
+      // w = mu^(lo+1) in Montgomery form, left-to-right square and multiply
+      u32 e = lo + 1;
+      w = mu;
+      for (int bit = 30 - __builtin_clz(e); bit >= 0; bit--) {
+        w = fr_mont(w, w);
+        if ((e >> bit) & 1u) w = fr_mont(w, mu);
+      }
+    }
+    const fr r2 = fr_r2();
+    for (u32 i = lo; i < hi; i++) {
+      fr x = fr_mont(fr_load_be(a + (size_t)i * a_stride * 32), r2);
+      fr p = fr_mont(x, fr_load_be(b + (size_t)i * b_stride * 32));
+      if (weighted) {
+        p = fr_mont(p, w);
+        w = fr_mont(w, mu);
+      }
+      acc = fr_add(acc, p);
+    }
+  }
+  lds[threadIdx.x] = acc;
+  __syncthreads();
+  for (u32 d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) lds[threadIdx.x] = fr_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = lds[0];
+}
+// single block: out_be = sum of partials[0..m)
+__global__ void __launch_bounds__(256) k_fr_sum(const fr* __restrict__ partials, u32 m, uint8_t* __restrict__ out_be) {
+  __shared__ fr lds[256];
+  fr acc = fr_zero();
+  for (u32 i = threadIdx.x; i < m; i += 256) acc = fr_add(acc, partials[i]);
+  lds[threadIdx.x] = acc;
+  __syncthreads();
+  for (u32 d = 128; d > 0; d >>= 1) {
+    if (threadIdx.x < d) lds[threadIdx.x] = fr_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) fr_store_be(out_be, lds[0]);
+}

@@ -15,6 +15,7 @@
 // go/bp/util.go:185-195), k_fold_points (generator folding, go/bp/main.go:355-356).
 #pragma once
 #include "g1.cuh"
+#include "fr.cuh"
 
 #define NOKEY 0xffffffffu
 
@@ -128,8 +129,8 @@ __device__ __forceinline__ u32 recode_carry_into(const u32 k[8], u32 w, u32 c) {
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 nb,
                                                     u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride, u32 tile_len,
-                                                    u32* __restrict__ hist, const u32* __restrict__ offsets,
-                                                    u32* __restrict__ sval) {
+                                                    u32 sc_stride, u32* __restrict__ hist,
+                                                    const u32* __restrict__ offsets, u32* __restrict__ sval) {
   extern __shared__ u32 lds[];
   const u32 tile = blockIdx.x, set = blockIdx.y, ntiles = gridDim.x;
   u32* h = hist + ((size_t)set * ntiles + tile) * nb;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
   u32 hi = (n - lo > tile_len) ? lo + tile_len : n;
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 k[8];
-    scalar_load_be(k, scalars_be + (size_t)i * 32);
+    scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
     bool neg = scalar_reduce_signed(k);
     // with a table one workgroup bins every window of its scalars; without, only window `set`
     const u32 w_lo = precomp ? 0u : set, w_hi = precomp ? W : set + 1u;
@@ -203,12 +204,12 @@ __global__ void __launch_bounds__(256) k_tile_scan(u32* __restrict__ hist, u32 n
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W,
                                                 u32 nb, u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride,
-                                                u32* __restrict__ counts, u32* __restrict__ rank,
+                                                u32 sc_stride, u32* __restrict__ counts, u32* __restrict__ rank,
                                                 const u32* __restrict__ offsets, u32* __restrict__ sval) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 k[8];
-  scalar_load_be(k, scalars_be + (size_t)i * 32);
+  scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
   bool neg = scalar_reduce_signed(k);
   u32 carry = 0;
   for (u32 w = 0; w < W; w++) {

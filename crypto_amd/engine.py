@@ -52,6 +52,37 @@ class Bases:
             pass
 
 
+class FrVec:
+    """Device-resident vector of scalars mod bn256.Order (a []*big.Int uploaded once)."""
+
+    def __init__(self, eng: "Engine", handle):
+        self.eng, self.h = eng, handle
+
+    def __len__(self) -> int:
+        return self.eng.lib.bn256_fr_len(self.h)
+
+    def download(self, off: int = 0, n: int | None = None) -> list[int]:
+        n = len(self) - off if n is None else n
+        buf = C.create_string_buffer(32 * max(n, 1))
+        self.eng._chk(self.eng.lib.bn256_fr_download(self.eng.ctx, self.h, off, n, buf))
+        raw = buf.raw
+        return [int.from_bytes(raw[32 * i:32 * i + 32], "big") for i in range(n)]
+
+    def device_ptr(self) -> int:
+        return self.eng.lib.bn256_fr_device_ptr(self.h) or 0
+
+    def free(self) -> None:
+        if self.h:
+            self.eng.lib.bn256_fr_free(self.eng.ctx, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.lib = _lib.load()
@@ -178,6 +209,39 @@ class Engine:
         self._chk(self.lib.bn256_fold2(self.ctx, lo.h, lo_off, n_lo, hi.h, hi_off, n_hi, stride,
                                        int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"), C.byref(h)))
         return Bases(self, h)
+
+    # Fr vectors on the device (go/bp/util.go:106-163, go/bppp/util.go:143-176,237-277) -----
+    def fr_upload(self, scalars: Sequence[int] | bytes) -> FrVec:
+        raw = scalars if isinstance(scalars, (bytes, bytearray)) else scalars_to_bytes(scalars)
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_fr_upload(self.ctx, bytes(raw), len(raw) // 32, C.byref(h)))
+        return FrVec(self, h)
+
+    def fr_random(self, seed: int, n: int, first: int = 0) -> FrVec:
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_fr_random(self.ctx, seed, first, n, C.byref(h)))
+        return FrVec(self, h)
+
+    def fr_fold(self, a: FrVec, a_off: int, n_a: int, b: FrVec, b_off: int, n_b: int, s_a: int, s_b: int,
+                stride: int = 1) -> FrVec:
+        """out[i] = s_a*a[a_off+i*stride] + s_b*b[b_off+i*stride], a missing side reads 0."""
+        h = C.c_void_p()
+        self._chk(self.lib.bn256_fr_fold(self.ctx, a.h, a_off, n_a, b.h, b_off, n_b, stride,
+                                         int(s_a).to_bytes(32, "big"), int(s_b).to_bytes(32, "big"), C.byref(h)))
+        return FrVec(self, h)
+
+    def fr_dot(self, a: FrVec, a_off: int, a_stride: int, n_a: int, b: FrVec, b_off: int, b_stride: int, n_b: int,
+               mu: int | None = None) -> int:
+        """vectorMul (mu None) / weightVectorMul (weights mu^(i+1)) over views."""
+        out = C.create_string_buffer(32)
+        mub = None if mu is None else int(mu).to_bytes(32, "big")
+        self._chk(self.lib.bn256_fr_dot(self.ctx, a.h, a_off, a_stride, n_a, b.h, b_off, b_stride, n_b, mub, out))
+        return int.from_bytes(out.raw, "big")
+
+    def msm_fr(self, bases: Bases, off: int, stride: int, n: int, v: FrVec, v_off: int = 0, v_stride: int = 1) -> bytes:
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm_fr(self.ctx, bases.h, off, stride, n, v.h, v_off, v_stride, out))
+        return out.raw
 
     def g1_sum(self, pts: Sequence[bytes]) -> bytes:
         out = C.create_string_buffer(64)

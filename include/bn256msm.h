@@ -107,6 +107,39 @@ int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_
 int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, int flags, bn256_bases** out);
 int bn256_random_scalars(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, void* d_out_be);
 
+/* ---- Fr vectors resident in HBM: the prover's scalar algebra ----------
+ * A bn256_frvec is a []*big.Int reduced mod bn256.Order, stored as the reference's own scalar
+ * encoding (32-byte big-endian, scalarTo32Byte go/bp/util.go:209-220), so the MSM kernels
+ * consume it in place.  Views are (off, stride, n): element i is v[off + i * stride]. */
+typedef struct bn256_frvec bn256_frvec;
+int bn256_fr_upload(bn256_ctx* ctx, const uint8_t* scalars_be, size_t n, bn256_frvec** out);
+int bn256_fr_random(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, bn256_frvec** out); /* = bn256_random_scalars */
+int bn256_fr_download(bn256_ctx* ctx, const bn256_frvec* v, size_t off, size_t n, uint8_t* scalars_be);
+size_t bn256_fr_len(const bn256_frvec* v);
+const void* bn256_fr_device_ptr(const bn256_frvec* v);
+void bn256_fr_free(bn256_ctx* ctx, bn256_frvec* v);
+
+/* out[i] = s_a * a[a_off + i*stride] + s_b * b[b_off + i*stride] mod n for i < max(n_a, n_b); a
+ * side that has run out reads 0.  Replaces vectorAdd(vectorMulOnScalar(..), vectorMulOnScalar(..)):
+ * IPA a' = x a_lo + x^-1 a_hi (go/bp/main.go:357-358, stride 1), WNLA l' = l0 + y l1 and
+ * n' = rho^-1 n0 + y n1 over reduceVector's even/odd halves (go/bppp/docs_test.go:1318-1319,
+ * go/bppp/util.go:198-211,245-260, stride 2). */
+int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t n_a, const bn256_frvec* b,
+                  size_t b_off, size_t n_b, size_t stride, const uint8_t s_a_be[32], const uint8_t s_b_be[32],
+                  bn256_frvec** out);
+
+/* out = sum_i a_i * b_i * w_i mod n over the shorter view (the other is zero-padded), with
+ * w_i = 1 when mu_be is NULL -- vectorMul, go/bp/util.go:132-142, go/bppp/util.go:143-157 --
+ * and w_i = mu^(i+1) otherwise -- weightVectorMul, go/bppp/util.go:159-176. */
+int bn256_fr_dot(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t a_stride, size_t n_a,
+                 const bn256_frvec* b, size_t b_off, size_t b_stride, size_t n_b, const uint8_t* mu_be,
+                 uint8_t out_be[32]);
+
+/* bn256_msm over views: sum_i v[v_off + i*v_stride] * b[off + i*stride], scalars never leave
+ * the device (vectorPointScalarMul on reducePoints / reduceVector halves). */
+int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n, const bn256_frvec* v,
+                 size_t v_off, size_t v_stride, uint8_t out_xy_be[64]);
+
 /* Host-side sum of k marshalled points (combination of per-GPU partial MSMs). */
 int bn256_g1_sum(const uint8_t* xy_be, size_t k, uint8_t out_xy_be[64]);
 

@@ -1,0 +1,157 @@
+"""GPU parity tests of the device Fr vector kernels (include/bn256msm.h, bn256_fr_*) against
+the oracle's restatement of go/bp/util.go:106-163 and go/bppp/util.go:143-176,198-211,245-260.
+Integer work: bit-exact."""
+import random
+
+import pytest
+
+import bn256_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+N = ref.N
+
+
+def _vals(rng, n, edge=True):
+    v = [rng.randrange(N) for _ in range(n)]
+    if edge and n >= 6:
+        v[0], v[1], v[2], v[3] = 0, 1, N - 1, (N - 1) // 2
+    return v
+
+
+def test_upload_download_and_reduction(eng):
+    rng = random.Random(1)
+    v = _vals(rng, 37)
+    h = eng.fr_upload(v)
+    assert len(h) == 37
+    assert h.download() == v
+    assert h.download(5, 3) == v[5:8]
+    h.free()
+    e = eng.fr_upload([])
+    assert len(e) == 0 and e.download() == []
+
+
+def test_fr_random_is_the_synthetic_stream(eng, orc):
+    h = eng.fr_random(0x5EED0002, 300, first=7)
+    raw = b"".join(x.to_bytes(32, "big") for x in h.download())
+    assert raw == orc.synth_scalars(0x5EED0002, 307)[32 * 7:]
+
+
+# Small literals checkable by hand.  The reference pins no vectorMul / weightVectorMul output of
+# its own (go/bppp/util_test.go pins only the poly* helpers); go/bp/docs_test.go:389-392 is the
+# one literal inner product it mentions.
+def test_small_literal_values(eng):
+    a = eng.fr_upload([1, 2, 3, 4])
+    b = eng.fr_upload([4, 3, 2, 1])
+    assert eng.fr_dot(a, 0, 1, 4, b, 0, 1, 4) == 20 == ref.vector_mul_bppp([1, 2, 3, 4], [4, 3, 2, 1])
+    assert eng.fr_dot(a, 0, 1, 4, b, 0, 1, 4, mu=2) == ref.weight_vector_mul([1, 2, 3, 4], [4, 3, 2, 1], 2)
+    # go/bp/docs_test.go:389-392 (the comment there says 39; vectorMul returns 43, see test_oracle.py)
+    x = eng.fr_upload([1, 2, 3, 4, 5])
+    y = eng.fr_upload([5, 4, 3, 2, 4])
+    assert eng.fr_dot(x, 0, 1, 5, y, 0, 1, 5) == ref.vector_mul([1, 2, 3, 4, 5], [5, 4, 3, 2, 4])
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 256, 257, 5000, 70001])
+def test_dot_matches_oracle(eng, n):
+    rng = random.Random(n)
+    a, b = _vals(rng, n), _vals(rng, n)
+    mu = rng.randrange(1, N)
+    ha, hb = eng.fr_upload(a), eng.fr_upload(b)
+    assert eng.fr_dot(ha, 0, 1, n, hb, 0, 1, n) == ref.vector_mul(a, b)
+    assert eng.fr_dot(ha, 0, 1, n, hb, 0, 1, n, mu=mu) == ref.weight_vector_mul(a, b, mu)
+    assert eng.fr_dot(ha, 0, 1, n, ha, 0, 1, n, mu=N - 1) == ref.weight_vector_mul(a, a, N - 1)
+    assert eng.fr_dot(ha, 0, 1, n, hb, 0, 1, n, mu=0) == 0
+    assert eng.fr_dot(ha, 0, 1, n, hb, 0, 1, n, mu=1) == ref.vector_mul(a, b)
+
+
+@pytest.mark.parametrize("n", [2, 3, 10, 11, 4097])
+def test_even_odd_views(eng, n):
+    """reduceVector halves (go/bppp/util.go:198-211) as stride-2 views, ragged for odd n."""
+    rng = random.Random(100 + n)
+    a, b = _vals(rng, n, edge=False), _vals(rng, n, edge=False)
+    ha, hb = eng.fr_upload(a), eng.fr_upload(b)
+    a0, a1 = ref.reduce_vector(a)
+    b0, b1 = ref.reduce_vector(b)
+    mu = rng.randrange(N)
+    n0, n1 = len(a0), len(a1)
+    assert eng.fr_dot(ha, 0, 2, n0, hb, 1, 2, n1) == ref.vector_mul_bppp(a0, b1)
+    assert eng.fr_dot(ha, 1, 2, n1, hb, 0, 2, n0) == ref.vector_mul_bppp(a1, b0)
+    assert eng.fr_dot(ha, 0, 2, n0, hb, 1, 2, n1, mu=mu) == ref.weight_vector_mul(a0, b1, mu)
+    assert eng.fr_dot(ha, 1, 2, n1, ha, 1, 2, n1, mu=mu) == ref.weight_vector_mul(a1, a1, mu)
+    y, r = rng.randrange(N), rng.randrange(N)
+    got = eng.fr_fold(ha, 0, n0, ha, 1, n1, r, y, stride=2).download()
+    exp = ref.vector_add_bppp(ref.vector_mul_on_scalar(a0, r), ref.vector_mul_on_scalar(a1, y))
+    assert got == exp
+    got = eng.fr_fold(ha, 0, n0, ha, 1, n1, 1, y, stride=2).download()
+    assert got == ref.vector_add_bppp(a0, ref.vector_mul_on_scalar(a1, y))
+
+
+def test_ipa_halves_fold(eng):
+    """a' = x a_lo + x^-1 a_hi, go/bp/main.go:357-358."""
+    rng = random.Random(5)
+    n = 64
+    a = _vals(rng, n)
+    x = rng.randrange(1, N)
+    xi = ref.finv(x)
+    ha = eng.fr_upload(a)
+    got = eng.fr_fold(ha, 0, n // 2, ha, n // 2, n // 2, x, xi).download()
+    exp = ref.vector_add(ref.vector_mul_on_scalar(a[:n // 2], x), ref.vector_mul_on_scalar(a[n // 2:], xi))
+    assert got == exp
+    # scalars >= n are reduced, not rejected
+    got2 = eng.fr_fold(ha, 0, n // 2, ha, n // 2, n // 2, x + N if x + N < 2**256 else x, xi).download()
+    assert got2 == exp
+
+
+def test_range_errors(eng):
+    import crypto_amd
+    h = eng.fr_upload([1, 2, 3])
+    with pytest.raises(crypto_amd.BN256Error) as e:
+        eng.fr_dot(h, 0, 1, 4, h, 0, 1, 3)
+    assert e.value.code == -2
+    with pytest.raises(crypto_amd.BN256Error) as e:
+        eng.fr_fold(h, 1, 2, h, 0, 3, 1, 1, stride=2)   # needs h[1], h[3]
+    assert e.value.code == -2
+    with pytest.raises(crypto_amd.BN256Error):
+        eng.fr_dot(h, 0, 0, 1, h, 0, 1, 1)              # zero stride
+
+
+@pytest.mark.parametrize("n,flags", [(1, 0), (33, 0), (1000, 0), (1000, 1), (20000, 1)])
+def test_msm_over_device_scalars(eng, orc, n, flags):
+    seed_b, seed_s = 0xB0 + n, 0x50 + n
+    bases = eng.random_bases(seed_b, n, flags=flags)
+    v = eng.fr_random(seed_s, n)
+    exp = orc.msm(orc.synth_bases(seed_b, n), orc.synth_scalars(seed_s, n))
+    assert eng.msm_fr(bases, 0, 1, n, v) == exp
+    # stride-2 views on both sides: <v_odd, G_even>
+    if n >= 4 and not flags:
+        pts = bases.download()
+        sc = v.download()
+        g0 = pts[0::2]
+        s1 = sc[1::2]
+        m = min(len(g0), len(s1))
+        exp2 = orc.msm(b"".join(g0[:m]), b"".join(s.to_bytes(32, "big") for s in s1[:m]))
+        assert eng.msm_fr(bases, 0, 2, m, v, 1, 2) == exp2
+
+
+def test_large_dot_linearity(eng):
+    """2^20 elements: <a, b> with weights against the oracle on a sparse b, and bilinearity."""
+    n = 1 << 20
+    a = eng.fr_random(11, n)
+    rng = random.Random(9)
+    idx = sorted(rng.sample(range(n), 50))
+    bvals = {i: rng.randrange(N) for i in idx}
+    braw = bytearray(32 * n)
+    for i, x in bvals.items():
+        braw[32 * i:32 * i + 32] = x.to_bytes(32, "big")
+    b = eng.fr_upload(bytes(braw))
+    mu = rng.randrange(N)
+    av = {i: a.download(i, 1)[0] for i in idx}
+    exp = sum(av[i] * bvals[i] for i in idx) % N
+    assert eng.fr_dot(a, 0, 1, n, b, 0, 1, n) == exp
+    expw = sum(av[i] * bvals[i] * pow(mu, i + 1, N) for i in idx) % N
+    assert eng.fr_dot(a, 0, 1, n, b, 0, 1, n, mu=mu) == expw
+    # <a, s*a + t*a> = (s + t) <a, a>
+    s, t = rng.randrange(N), rng.randrange(N)
+    c = eng.fr_fold(a, 0, n, a, 0, n, s, t)
+    aa = eng.fr_dot(a, 0, 1, n, a, 0, 1, n)
+    assert eng.fr_dot(a, 0, 1, n, c, 0, 1, n) == (s + t) * aa % N
