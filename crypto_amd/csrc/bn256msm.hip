@@ -34,7 +34,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -178,10 +178,30 @@ static bn256_bases* bases_alloc(size_t n, int levels, int c, int* rc) {
   return b;
 }
 
+// Element-wise kernels leave XYZZ results in a scratch array; xyzz_scratch() reserves it (plus the
+// prefix-product array) and normalize_into() converts to affine with one inversion per chunk.
+static int xyzz_scratch(bn256_ctx* ctx, size_t n, xyzz_mem** out) {
+  int rc;
+  if ((rc = ws_reserve(ctx, WS_BUCKETS, n * sizeof(xyzz_mem))) || (rc = ws_reserve(ctx, WS_PARTIALS, n * 9 * sizeof(i32))))
+    return rc;
+  *out = (xyzz_mem*)ctx->ws[WS_BUCKETS];
+  return BN256_OK;
+}
+static void normalize_into(bn256_ctx* ctx, const xyzz_mem* in, aff_mem* out, size_t n) {
+  u32 B = (u32)std::min<size_t>(32, std::max<size_t>(1, n / 65536));
+  size_t threads = (n + B - 1) / B;
+  hipLaunchKernelGGL(k_batch_to_affine, dim3(nblocks(threads, 256)), dim3(256), 0, ctx->stream, in, out,
+                     (i32*)ctx->ws[WS_PARTIALS], (u32)n, B);
+}
+
 static int bases_precompute(bn256_ctx* ctx, bn256_bases* b) {
+  xyzz_mem* xs;
+  int rc = xyzz_scratch(ctx, b->n, &xs);
+  if (rc) return rc;
   for (int l = 1; l < b->levels; l++) {
     hipLaunchKernelGGL(k_precompute_level, dim3(nblocks(b->n, 256)), dim3(256), 0, ctx->stream,
-                       b->d + (size_t)(l - 1) * b->n, b->d + (size_t)l * b->n, (u32)b->n, (u32)b->c);
+                       b->d + (size_t)(l - 1) * b->n, xs, (u32)b->n, (u32)b->c);
+    normalize_into(ctx, xs, b->d + (size_t)l * b->n, b->n);
   }
   HIPCHK(hipGetLastError());
   return BN256_OK;
@@ -458,6 +478,56 @@ extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* 
 }
 
 // ---------------------------------------------------------------------------- element-wise
+// Joint sparse form of (a mod n, b mod n); see jsf_arg in kernels.cuh.
+static void jsf_build(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg* out) {
+  static const uint64_t nw[4] = {0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL, 0xaa6fecb86184dc21ULL,
+                                 0x8fb501e34aa387f9ULL};
+  uint64_t k[2][5];
+  const uint8_t* src[2] = {a_be, b_be};
+  for (int s = 0; s < 2; s++) {
+    hostg1::be_load(k[s], src[s]);
+    k[s][4] = 0;
+    bool ge = true;
+    for (int i = 3; i >= 0; i--)
+      if (k[s][i] != nw[i]) { ge = k[s][i] > nw[i]; break; }
+    if (ge) {
+      unsigned __int128 br = 0;
+      for (int i = 0; i < 4; i++) {
+        unsigned __int128 d = (unsigned __int128)k[s][i] - nw[i] - (uint64_t)br;
+        k[s][i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+      }
+    }
+  }
+  memset(out, 0, sizeof *out);
+  auto nonzero = [](const uint64_t* v) { return (v[0] | v[1] | v[2] | v[3] | v[4]) != 0; };
+  u32 len = 0;
+  while (nonzero(k[0]) || nonzero(k[1])) {
+    int u[2] = {0, 0};
+    for (int s = 0; s < 2; s++) {
+      uint64_t lo = k[s][0], other = k[1 - s][0];
+      if (lo & 1) {
+        u[s] = (lo & 3) == 1 ? 1 : -1;
+        if (((lo & 7) == 3 || (lo & 7) == 5) && (other & 3) == 2) u[s] = -u[s];
+      }
+    }
+    for (int s = 0; s < 2; s++) {
+      if (u[s] == 1) {
+        k[s][0] -= 1;  // k odd: no borrow
+      } else if (u[s] == -1) {
+        for (int i = 0; i < 5; i++)
+          if (++k[s][i] != 0) break;
+      }
+      for (int i = 0; i < 4; i++) k[s][i] = (k[s][i] >> 1) | (k[s][i + 1] << 63);
+      k[s][4] >>= 1;
+    }
+    u32 nib = (u32)(u[0] == 0 ? 0 : (u[0] == 1 ? 1 : 3)) | ((u32)(u[1] == 0 ? 0 : (u[1] == 1 ? 1 : 3)) << 2);
+    out->w[len >> 3] |= nib << ((len & 7) * 4);
+    len++;
+  }
+  out->len = len;
+}
+
 extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
                                       const uint8_t* scalars_be, int broadcast, bn256_bases** out) {
   if (!ctx || !in || !out || (!scalars_be && n)) return BN256_EINVAL;
@@ -467,13 +537,26 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
   HIPCHK(hipSetDevice(ctx->device));
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
-  if (n) {
-    size_t sb = broadcast ? 32 : n * 32;
+  xyzz_mem* xs = nullptr;
+  if (n && (rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
+  if (n && broadcast) {
+    // one scalar for every point (vectorPointMulOnScalar): the uniform NAF chain of the fold kernel
+    static const uint8_t zero[32] = {0};
+    jsf_arg jsf;
+    jsf_build(scalars_be, zero, &jsf);
+    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream,
+                       (const aff_mem*)(in->d + off), (const aff_mem*)(in->d + off), 1u, jsf, xs, (u32)n, 0u);
+    normalize_into(ctx, xs, r->d, n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+  } else if (n) {
+    size_t sb = n * 32;
     if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) { bn256_bases_free(ctx, r); return rc; }
     hipError_t e = hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(in->d + off),
-                         (const uint8_t*)ctx->ws[WS_SCALARS], r->d, (u32)n, (u32)(broadcast != 0), 0u);
+                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
+      normalize_into(ctx, xs, r->d, n);
       e = hipStreamSynchronize(ctx->stream);
     }
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
@@ -493,8 +576,11 @@ extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
   if (n) {
+    xyzz_mem* xs;
+    if ((rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
     hipLaunchKernelGGL(k_add_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(a->d + aoff),
-                       (const aff_mem*)(b->d + boff), r->d, (u32)n);
+                       (const aff_mem*)(b->d + boff), xs, (u32)n);
+    normalize_into(ctx, xs, r->d, n);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
   }
@@ -515,16 +601,15 @@ extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off,
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
   if (n) {
-    if ((rc = ws_reserve(ctx, WS_SCALARS, 64))) { bn256_bases_free(ctx, r); return rc; }
-    uint8_t* ds = (uint8_t*)ctx->ws[WS_SCALARS];
-    hipError_t e = hipMemcpyAsync(ds, s_lo_be, 32, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ds + 32, s_hi_be, 32, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
-                         (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride,
-                         (const uint8_t*)ds, (const uint8_t*)(ds + 32), r->d, (u32)n_lo, (u32)n_hi);
-      e = hipStreamSynchronize(ctx->stream);
-    }
+    xyzz_mem* xs;
+    if ((rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
+    jsf_arg jsf;
+    jsf_build(s_lo_be, s_hi_be, &jsf);
+    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream,
+                       (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, jsf, xs,
+                       (u32)n_lo, (u32)n_hi);
+    normalize_into(ctx, xs, r->d, n);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
   }
   *out = r;
@@ -568,7 +653,9 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
     g0[31] = 1;
     uint64_t y[4] = {hostg1::kP[0] - 2, hostg1::kP[1], hostg1::kP[2], hostg1::kP[3]};
     hostg1::be_store(g0 + 32, y);
-    if ((rc = ws_reserve(ctx, WS_TMP, 64 + sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, n * 32))) {
+    xyzz_mem* xs = nullptr;
+    if ((rc = ws_reserve(ctx, WS_TMP, 64 + sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, n * 32)) ||
+        (rc = xyzz_scratch(ctx, n, &xs))) {
       bn256_bases_free(ctx, b);
       return rc;
     }
@@ -581,7 +668,8 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
       hipLaunchKernelGGL(k_synth_scalars, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
                          (uint8_t*)ctx->ws[WS_SCALARS], (u64)seed, (u64)first, (u32)n, 1u);
       hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
-                         (const uint8_t*)ctx->ws[WS_SCALARS], b->d, (u32)n, 0u, 1u);
+                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
+      normalize_into(ctx, xs, b->d, n);
       e = hipStreamSynchronize(ctx->stream);
     }
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, b); return BN256_EHIP; }
@@ -765,6 +853,50 @@ extern "C" int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, si
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt r;
   rc = msm_core(ctx, b, off, stride, n, v->d + v_off * 32, &r, v_stride);
+  if (rc) return rc;
+  hostg1::marshal(out_xy_be, r);
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                                  const size_t* stride, const size_t* n, const bn256_frvec* const* v,
+                                  const size_t* v_off, const size_t* v_stride, const uint8_t* const* scale_be,
+                                  uint8_t out_xy_be[64]) {
+  if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
+  size_t total = 0;
+  int rc;
+  for (int i = 0; i < k; i++) {
+    if (!b[i] || !v[i]) return BN256_EINVAL;
+    if ((rc = range_check(b[i], off[i], n[i], stride[i])) || (rc = fr_range_check(v[i], v_off[i], n[i], v_stride[i]))) return rc;
+    total += n[i];
+  }
+  memset(out_xy_be, 0, 64);
+  if (total == 0) return BN256_OK;
+  if (total >= (1ull << 31)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ws_reserve(ctx, WS_GATHER, total * sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, total * 32))) return rc;
+  aff_mem* pts = (aff_mem*)ctx->ws[WS_GATHER];
+  uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
+  size_t pos = 0;
+  for (int i = 0; i < k; i++) {
+    if (!n[i]) continue;
+    const uint8_t* s_be = scale_be ? scale_be[i] : nullptr;
+    fr_arg scale;
+    memset(&scale, 0, sizeof scale);
+    if (s_be) scale = fr_arg_canon(fr_arg_from_be(s_be));
+    hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(n[i], 256)), dim3(256), 0, ctx->stream,
+                       (const uint4*)(b[i]->d + off[i]), (u32)stride[i], (uint4*)(pts + pos),
+                       (const uint8_t*)(v[i]->d + v_off[i] * 32), (u32)v_stride[i], scale, (u32)(s_be != nullptr),
+                       sc + pos * 32, (u32)n[i]);
+    pos += n[i];
+  }
+  bn256_bases tmp;
+  tmp.d = pts;
+  tmp.n = total;
+  tmp.levels = 1;
+  tmp.c = 0;
+  hostg1::Pt r;
+  rc = msm_core(ctx, &tmp, 0, 1, total, sc, &r);
   if (rc) return rc;
   hostg1::marshal(out_xy_be, r);
   return BN256_OK;

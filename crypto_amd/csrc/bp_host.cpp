@@ -7,6 +7,8 @@
 // This is product code; it shares nothing with oracle/.
 #include <cstdint>
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <stdexcept>
@@ -661,10 +663,6 @@ FrVec padTo(FrVec a, size_t n) {
   while (a.size() < n) a.push_back(kFrZero);
   return a;
 }
-FrVec vectorAddPP(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:245-260
-  size_t n = std::max(a.size(), b.size());
-  return vectorAdd(padTo(a, n), padTo(b, n));
-}
 Fr vectorMulPP(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:143-157
   size_t n = std::max(a.size(), b.size());
   return vectorMul(padTo(a, n), padTo(b, n));
@@ -678,11 +676,6 @@ Fr weightVectorMul(const FrVec& a_in, const FrVec& b_in, const Fr& mu) {  // go/
     e = mul(e, mu);
   }
   return res;
-}
-void reduceVector(const FrVec& v, FrVec& v0, FrVec& v1) {  // go/bppp/util.go:198-211
-  v0.clear();
-  v1.clear();
-  for (size_t i = 0; i < v.size(); i++) (i % 2 == 0 ? v0 : v1).push_back(v[i]);
 }
 // values(n) of go/bppp/util.go:11-25: rand.Int is drawn and discarded, the value is 2
 FrVec valuesPP(ByteStream* rd, int n) {
@@ -720,43 +713,167 @@ Point msmStrided(bn256_ctx* ctx, const std::vector<SSeg>& segs) {
                               out.b));
   return out;
 }
+struct DevFr {  // a []*big.Int resident in HBM (32-byte big-endian, reduced mod Order)
+  bn256_ctx* ctx = nullptr;
+  bn256_frvec* h = nullptr;
+  size_t n = 0;
+  DevFr() {}
+  DevFr(bn256_ctx* c, bn256_frvec* v) : ctx(c), h(v), n(bn256_fr_len(v)) {}
+  DevFr(bn256_ctx* c, const FrVec& a) : ctx(c) {
+    std::vector<uint8_t> raw = scalarBytes(a);
+    chk(bn256_fr_upload(c, raw.data(), a.size(), &h));
+    n = a.size();
+  }
+  DevFr(const DevFr&) = delete;
+  DevFr& operator=(const DevFr&) = delete;
+  DevFr(DevFr&& o) noexcept : ctx(o.ctx), h(o.h), n(o.n) { o.h = nullptr; }
+  DevFr& operator=(DevFr&& o) noexcept {
+    if (this != &o) {
+      if (h) bn256_fr_free(ctx, h);
+      ctx = o.ctx; h = o.h; n = o.n; o.h = nullptr;
+    }
+    return *this;
+  }
+  ~DevFr() {
+    if (h) bn256_fr_free(ctx, h);
+  }
+  FrVec download() const {
+    std::vector<uint8_t> raw(32 * std::max<size_t>(n, 1));
+    chk(bn256_fr_download(ctx, h, 0, n, raw.data()));
+    FrVec r(n);
+    for (size_t i = 0; i < n; i++) r[i] = fr_from_be(&raw[32 * i]);
+    return r;
+  }
+};
+// A reduceVector / reducePoints half (go/bppp/util.go:198-226) as a view: elements off, off+2, ...
+struct View {
+  size_t off, stride, len;
+};
+View evens(size_t n) { return {0, 2, (n + 1) / 2}; }
+View odds(size_t n) { return {n > 1 ? (size_t)1 : 0, 2, n / 2}; }
+View whole(size_t n) { return {0, 1, n}; }
+
+// vectorMul / weightVectorMul over views, zero-padded to the longer side (go/bppp/util.go:143-176)
+Fr devDot(bn256_ctx* ctx, const DevFr& a, View va, const DevFr& b, View vb, const Fr* mu) {
+  uint8_t mub[32], out[32];
+  if (mu) fr_to_be(mub, *mu);
+  chk(bn256_fr_dot(ctx, a.h, va.off, va.stride, va.len, b.h, vb.off, vb.stride, vb.len, mu ? mub : nullptr, out));
+  return fr_from_be(out);
+}
+// vectorAdd(vectorMulOnScalar(v0, s0), vectorMulOnScalar(v1, s1)) on the halves of v (go/bppp/util.go:237-260)
+DevFr devFoldHalves(bn256_ctx* ctx, const DevFr& v, const Fr& s0, const Fr& s1) {
+  uint8_t b0[32], b1[32];
+  fr_to_be(b0, s0);
+  fr_to_be(b1, s1);
+  View e = evens(v.n), o = odds(v.n);
+  bn256_frvec* r = nullptr;
+  chk(bn256_fr_fold(ctx, v.h, e.off, e.len, v.h, o.off, o.len, 2, b0, b1, &r));
+  return DevFr(ctx, r);
+}
+// BP++ vectorPointScalarMul semantics on views (go/bppp/util.go:178-196): an empty view is the
+// identity, the shorter side decides the length (zero padding / truncation).
+// wall-clock split of the last wnla() by kind of work (BP_PROFILE=1 prints it to stderr)
+struct Prof {
+  double t[6] = {0, 0, 0, 0, 0, 0};
+  static double now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  }
+};
+enum { PF_DOT, PF_MSM, PF_HOSTPT, PF_PTFOLD, PF_FRFOLD, PF_OTHER };
+
+// Sum of BP++ vectorPointScalarMul terms over views as ONE device MSM; scale (optional) multiplies
+// the segment's scalars on the device.
+struct FSeg {
+  const DevPoints* g;
+  View vg;
+  const DevFr* a;
+  View va;
+  const Fr* scale;
+};
+Point devMsmFused(bn256_ctx* ctx, const std::vector<FSeg>& segs) {
+  std::vector<const bn256_bases*> hs;
+  std::vector<const bn256_frvec*> vs;
+  std::vector<size_t> off, stride, ns, voff, vstride;
+  std::vector<std::vector<uint8_t>> scal;
+  std::vector<const uint8_t*> sptr;
+  for (const FSeg& s : segs) {
+    size_t n = std::min(s.vg.len, s.va.len);
+    if (n == 0) continue;
+    hs.push_back(s.g->h);
+    vs.push_back(s.a->h);
+    off.push_back(s.vg.off);
+    stride.push_back(s.vg.stride);
+    ns.push_back(n);
+    voff.push_back(s.va.off);
+    vstride.push_back(s.va.stride);
+    scal.emplace_back();
+    if (s.scale) {
+      scal.back().resize(32);
+      fr_to_be(scal.back().data(), *s.scale);
+    }
+  }
+  for (auto& v : scal) sptr.push_back(v.empty() ? nullptr : v.data());
+  Point out;
+  chk(bn256_msm_fr_multi(ctx, (int)hs.size(), hs.data(), off.data(), stride.data(), ns.data(), vs.data(), voff.data(),
+                         vstride.data(), sptr.data(), out.b));
+  return out;
+}
+
 struct WnlaResult {
   std::vector<Point> X, R;
   FrVec l, n;
   bool verified = false;
 };
-// wnla, go/bppp/docs_test.go:1269-1338 (recursion as a loop; G, H stay on device, the even/odd
-// halves of reducePoints are stride-2 views)
-WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, FrVec c, Point C, Fr ro, Fr mu, FrVec l,
-                FrVec n, ByteStream* rd) {
+// wnla, go/bppp/docs_test.go:1269-1338 (recursion as a loop).  G, H, c, l, n all stay in HBM; the
+// even/odd halves of reducePoints / reduceVector are stride-2 views; per round only the 64-byte
+// X, R and a few 32-byte inner products cross PCIe.  <rho*n1, G0> is taken as rho*<n1, G0> (one
+// host scalar mult of the 64-byte result instead of a scaled copy of the vector).
+WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr c, Point C, Fr ro, Fr mu, DevFr l,
+                DevFr n, ByteStream* rd) {
   WnlaResult res;
+  Prof pf;
+  double tp = Prof::now();
+  auto lap = [&](int k) {
+    double t = Prof::now();
+    pf.t[k] += t - tp;
+    tp = t;
+  };
+  auto report = [&]() {
+    if (getenv("BP_PROFILE"))
+      fprintf(stderr, "[wnla] rounds=%zu ms: dot=%.2f msm=%.2f host_point=%.2f point_fold=%.2f fr_fold=%.2f other=%.2f\n",
+              res.X.size(), pf.t[PF_DOT], pf.t[PF_MSM], pf.t[PF_HOSTPT], pf.t[PF_PTFOLD], pf.t[PF_FRFOLD], pf.t[PF_OTHER]);
+  };
   for (;;) {
     Fr roinv = fr_inv(ro);
-    if (l.size() + n.size() < 6) {
-      Fr v = add(vectorMulPP(c, l), weightVectorMul(n, n, mu));
-      Point Cc = scalarMult(g, v);
-      Cc = pointAdd(Cc, msmStrided(ctx, {{&H, 0, 1, H.n, l}, {&G, 0, 1, G.n, n}}));
-      res.l = l;
-      res.n = n;
+    lap(PF_OTHER);
+    if (l.n + n.n < 6) {
+      Fr v = add(devDot(ctx, c, whole(c.n), l, whole(l.n), nullptr), devDot(ctx, n, whole(n.n), n, whole(n.n), &mu));
+      Point Cc = pointAdd(scalarMult(g, v), devMsmFused(ctx, {{&H, whole(H.n), &l, whole(l.n), nullptr},
+                                                                 {&G, whole(G.n), &n, whole(n.n), nullptr}}));
+      res.l = l.download();
+      res.n = n.download();
       res.verified = pointEq(Cc, C);
+      lap(PF_OTHER);
+      report();
       return res;
     }
     Fr y = valuesPP(rd, 1)[0];
-    FrVec c0, c1, l0, l1, n0, n1;
-    reduceVector(c, c0, c1);
-    reduceVector(l, l0, l1);
-    reduceVector(n, n0, n1);
-    size_t g0n = (G.n + 1) / 2, g1n = G.n / 2, h0n = (H.n + 1) / 2, h1n = H.n / 2;
-    FrVec l_ = vectorAddPP(l0, vectorMulOnScalar(l1, y));
-    FrVec n_ = vectorAddPP(vectorMulOnScalar(n0, roinv), vectorMulOnScalar(n1, y));
+    View c0 = evens(c.n), c1 = odds(c.n), l0 = evens(l.n), l1 = odds(l.n), n0 = evens(n.n), n1 = odds(n.n);
+    View G0 = evens(G.n), G1 = odds(G.n), H0 = evens(H.n), H1 = odds(H.n);
     Fr mu2 = mul(mu, mu);
-    Fr vx = add(mul(weightVectorMul(n0, n1, mu2), mul(fr_from_u64(2), roinv)), add(vectorMulPP(c0, l1), vectorMulPP(c1, l0)));
-    Fr vr = add(weightVectorMul(n1, n1, mu2), vectorMulPP(c1, l1));
-    Point X = pointAdd(scalarMult(g, vx), msmStrided(ctx, {{&H, 0, 2, h0n, l1},
-                                                            {&H, 1, 2, h1n, l0},
-                                                            {&G, 0, 2, g0n, vectorMulOnScalar(n1, ro)},
-                                                            {&G, 1, 2, g1n, vectorMulOnScalar(n0, roinv)}}));
-    Point R = pointAdd(scalarMult(g, vr), msmStrided(ctx, {{&H, 1, 2, h1n, l1}, {&G, 1, 2, g1n, n1}}));
+    Fr vx = add(mul(devDot(ctx, n, n0, n, n1, &mu2), mul(fr_from_u64(2), roinv)),
+                add(devDot(ctx, c, c0, l, l1, nullptr), devDot(ctx, c, c1, l, l0, nullptr)));
+    Fr vr = add(devDot(ctx, n, n1, n, n1, &mu2), devDot(ctx, c, c1, l, l1, nullptr));
+    lap(PF_DOT);
+    Point mx = devMsmFused(ctx, {{&H, H0, &l, l1, nullptr}, {&H, H1, &l, l0, nullptr}, {&G, G0, &n, n1, &ro},
+                                 {&G, G1, &n, n0, &roinv}});
+    Point mr = devMsmFused(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
+    lap(PF_MSM);
+    Point X = pointAdd(scalarMult(g, vx), mx);
+    Point R = pointAdd(scalarMult(g, vr), mr);
+    lap(PF_HOSTPT);
     res.X.push_back(X);
     res.R.push_back(R);
     // H_ = H0 (+) y*H1 ; G_ = ro*G0 (+) y*G1   (docs_test.go:1325-1326), ragged folds on device
@@ -765,21 +882,26 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, FrVec 
     fr_to_be(yb, y);
     fr_to_be(rob, ro);
     bn256_bases *hn = nullptr, *gn = nullptr;
-    chk(bn256_fold2(ctx, H.h, 0, h0n, H.h, H.n > 1 ? 1 : 0, h1n, 2, oneb, yb, &hn));
+    chk(bn256_fold2(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn));
     DevPoints Hn(ctx, hn);
-    chk(bn256_fold2(ctx, G.h, 0, g0n, G.h, G.n > 1 ? 1 : 0, g1n, 2, rob, yb, &gn));
+    chk(bn256_fold2(ctx, G.h, G0.off, G0.len, G.h, G1.off, G1.len, 2, rob, yb, &gn));
     DevPoints Gn(ctx, gn);
-    FrVec c_ = vectorAddPP(c0, vectorMulOnScalar(c1, y));
+    lap(PF_PTFOLD);
+    DevFr c_ = devFoldHalves(ctx, c, kFrOne, y);
+    DevFr l_ = devFoldHalves(ctx, l, kFrOne, y);
+    DevFr n_ = devFoldHalves(ctx, n, roinv, y);
+    lap(PF_FRFOLD);
     Point C_ = pointAdd(C, scalarMult(X, y));
     C_ = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
     G = std::move(Gn);
     H = std::move(Hn);
-    c = c_;
+    c = std::move(c_);
     C = C_;
     ro = mu;
     mu = mu2;
-    l = l_;
-    n = n_;
+    l = std::move(l_);
+    n = std::move(n_);
+    lap(PF_HOSTPT);
   }
 }
 
@@ -878,7 +1000,7 @@ extern "C" int bp_wnla_det(bn256_ctx* ctx, uint64_t seed, int nl, int nn, const 
     for (int i = 0; i < nn; i++) n[i] = fr_from_be(n_be + 32 * i);
     Fr v = add(vectorMulPP(c, l), weightVectorMul(n, n, mu));
     Point C = pointAdd(scalarMult(g, v), msmStrided(ctx, {{&H, 0, 1, H.n, l}, {&G, 0, 1, G.n, n}}));
-    WnlaResult r = wnla(ctx, g, std::move(G), std::move(H), c, C, ro, mu, l, n, &rd);
+    WnlaResult r = wnla(ctx, g, std::move(G), std::move(H), DevFr(ctx, c), C, ro, mu, DevFr(ctx, l), DevFr(ctx, n), &rd);
     std::vector<uint8_t> o(C.b, C.b + 64);
     auto u32be = [&](uint32_t k) {
       o.push_back((uint8_t)(k >> 24)); o.push_back((uint8_t)(k >> 16)); o.push_back((uint8_t)(k >> 8)); o.push_back((uint8_t)k);
@@ -925,15 +1047,18 @@ extern "C" int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_
     chk(bn256_random_bases(ctx, seed + 2, 0, 1, 0, &g1));
     DevPoints gdev(ctx, g1);
     Point g = gdev.at(0);
-    ByteStream rd{seed};
-    FrVec c = valuesPP(nullptr, (int)nl), l(nl), n(nn);
-    for (size_t i = 0; i < nl; i++) l[i] = rd.randInt();
-    for (size_t i = 0; i < nn; i++) n[i] = rd.randInt();
+    DevFr c(ctx, valuesPP(nullptr, (int)nl));
+    bn256_frvec *lh = nullptr, *nh = nullptr;
+    chk(bn256_fr_random(ctx, seed + 3, 0, nl, &lh));
+    DevFr l(ctx, lh);
+    chk(bn256_fr_random(ctx, seed + 4, 0, nn, &nh));
+    DevFr n(ctx, nh);
     Fr ro = fr_from_u64(2), mu = mul(ro, ro);
-    Fr v = add(vectorMulPP(c, l), weightVectorMul(n, n, mu));
-    Point C = pointAdd(scalarMult(g, v), msmStrided(ctx, {{&H, 0, 1, H.n, l}, {&G, 0, 1, G.n, n}}));
+    Fr v = add(devDot(ctx, c, whole(c.n), l, whole(l.n), nullptr), devDot(ctx, n, whole(n.n), n, whole(n.n), &mu));
+    Point C = pointAdd(scalarMult(g, v), devMsmFused(ctx, {{&H, whole(H.n), &l, whole(l.n), nullptr},
+                                                             {&G, whole(G.n), &n, whole(n.n), nullptr}}));
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    WnlaResult r = wnla(ctx, g, std::move(G), std::move(H), c, C, ro, mu, l, n, nullptr);
+    WnlaResult r = wnla(ctx, g, std::move(G), std::move(H), std::move(c), C, ro, mu, std::move(l), std::move(n), nullptr);
     clock_gettime(CLOCK_MONOTONIC, &t2);
     if (ms_setup) *ms_setup = (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
     if (ms_run) *ms_run = (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6;

@@ -205,3 +205,25 @@ __global__ void __launch_bounds__(256) k_fr_sum(const fr* __restrict__ partials,
   }
   if (threadIdx.x == 0) fr_store_be(out_be, lds[0]);
 }
+
+// Gathers one (points view, scalars view) segment into contiguous arrays so that several
+// segments become ONE MSM: dst_pts[i] = src_pts[i*pt_stride], dst_sc[i] = scale * src_sc[i*sc_stride]
+// (scale optional).  <rho * n1, G0> of the WNLA round (go/bppp/docs_test.go:1296-1306) is a
+// segment with scale = rho.
+__global__ void __launch_bounds__(256) k_gather_segment(const uint4* __restrict__ src_pts, u32 pt_stride,
+                                                        uint4* __restrict__ dst_pts, const uint8_t* __restrict__ src_sc,
+                                                        u32 sc_stride, fr_arg scale, u32 has_scale,
+                                                        uint8_t* __restrict__ dst_sc, u32 n) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* sp = src_pts + (size_t)i * pt_stride * 4;
+  uint4* dp = dst_pts + (size_t)i * 4;
+  uint4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+  dp[0] = a;
+  dp[1] = b;
+  dp[2] = c;
+  dp[3] = d;
+  fr x = fr_load_be(src_sc + (size_t)i * sc_stride * 32);
+  if (has_scale) x = fr_mont(x, fr_to_mont(fr_from_arg(scale)));
+  fr_store_be(dst_sc + (size_t)i * 32, x);
+}

@@ -513,26 +513,64 @@ __global__ void __launch_bounds__(256) k_points_to_be(const aff_mem* __restrict_
   scalar_store_be(out + (size_t)i * 64 + 32, wy);
 }
 
+// Batch normalisation XYZZ -> affine (Montgomery's trick): thread t owns points [tB, (t+1)B),
+// multiplies their ZZZ together (prefix products to `prefix`), inverts once, and walks back.
+// 7 multiplications per point + one ~380-multiplication inversion per B points, instead of one
+// inversion per point.  Used by every element-wise kernel below.
+__global__ void __launch_bounds__(256) k_batch_to_affine(const xyzz_mem* __restrict__ in, aff_mem* __restrict__ out,
+                                                         i32* __restrict__ prefix, u32 n, u32 B) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  u64 lo64 = (u64)t * B;
+  if (lo64 >= n) return;
+  u32 lo = (u32)lo64;
+  u32 hi = (n - lo > B) ? lo + B : n;
+  fe run = fe_one();
+  for (u32 i = lo; i < hi; i++) {
+    xyzz a;
+    xyzz_load(a, &in[i]);
+    if (!xyzz_is_inf(a)) run = fe_mul(run, a.zzz);
+#pragma unroll
+    for (int j = 0; j < 9; j++) prefix[(size_t)i * 9 + j] = run.v[j];
+  }
+  fe inv = fe_inv(run);
+  for (u32 i = hi; i-- > lo;) {
+    xyzz a;
+    xyzz_load(a, &in[i]);
+    if (xyzz_is_inf(a)) {
+      aff_store_inf(&out[i]);
+      continue;
+    }
+    fe prev = fe_one();
+    if (i > lo) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) prev.v[j] = prefix[(size_t)(i - 1) * 9 + j];
+    }
+    fe zi3 = fe_mul(inv, prev);   // 1 / ZZZ_i
+    inv = fe_mul(inv, a.zzz);
+    fe zi = fe_mul(a.zz, zi3);    // 1 / Z
+    fe zi2 = fe_sqr(zi);          // 1 / ZZ
+    fe x = fe_canon(fe_mul(a.x, zi2));
+    fe y = fe_canon(fe_mul(a.y, zi3));
+    aff_store(&out[i], x, y);
+  }
+}
+
 // next[i] = 2^c * prev[i]
-__global__ void __launch_bounds__(256) k_precompute_level(const aff_mem* __restrict__ prev, aff_mem* __restrict__ next,
+__global__ void __launch_bounds__(256) k_precompute_level(const aff_mem* __restrict__ prev, xyzz_mem* __restrict__ next,
                                                           u32 n, u32 c) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe x, y;
-  if (!aff_load(x, y, &prev[i], false)) {
-    aff_store_inf(&next[i]);
-    return;
-  }
   xyzz a, r;
-  xyzz_dbl_affine(a, x, y);
-  for (u32 j = 1; j < c; j++) {
-    xyzz_dbl(r, a);
-    a = r;
+  xyzz_set_inf(a);
+  if (aff_load(x, y, &prev[i], false)) {
+    xyzz_dbl_affine(a, x, y);
+    for (u32 j = 1; j < c; j++) {
+      xyzz_dbl(r, a);
+      a = r;
+    }
   }
-  if (xyzz_to_affine(x, y, a))
-    aff_store(&next[i], x, y);
-  else
-    aff_store_inf(&next[i]);
+  xyzz_store(&next[i], a);
 }
 
 // ------------------------------------------------------------------ element-wise point ops
@@ -557,27 +595,23 @@ __device__ __forceinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& 
 
 // out[i] = s_i * in[i]   (broadcast_scalar: s_0 for all; broadcast_point: in[0] for all)
 __global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ in, const uint8_t* __restrict__ scalars_be,
-                                                    aff_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
+                                                    xyzz_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
                                                     u32 broadcast_point) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe x, y;
-  if (!aff_load(x, y, &in[broadcast_point ? 0 : i], false)) {
-    aff_store_inf(&out[i]);
-    return;
-  }
-  u32 k[8];
-  scalar_load_be(k, scalars_be + (broadcast_scalar ? 0 : (size_t)i * 32));
   xyzz acc;
-  g1_scalar_mul(acc, x, y, k);
-  if (xyzz_to_affine(x, y, acc))
-    aff_store(&out[i], x, y);
-  else
-    aff_store_inf(&out[i]);
+  xyzz_set_inf(acc);
+  if (aff_load(x, y, &in[broadcast_point ? 0 : i], false)) {
+    u32 k[8];
+    scalar_load_be(k, scalars_be + (broadcast_scalar ? 0 : (size_t)i * 32));
+    g1_scalar_mul(acc, x, y, k);
+  }
+  xyzz_store(&out[i], acc);
 }
 
 __global__ void __launch_bounds__(256) k_add_points(const aff_mem* __restrict__ a, const aff_mem* __restrict__ b,
-                                                    aff_mem* __restrict__ out, u32 n) {
+                                                    xyzz_mem* __restrict__ out, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe x1, y1, x2, y2;
@@ -587,40 +621,71 @@ __global__ void __launch_bounds__(256) k_add_points(const aff_mem* __restrict__ 
   xyzz_set_inf(acc);
   if (f1) xyzz_madd(acc, x1, y1);
   if (f2) xyzz_madd(acc, x2, y2);
-  if (xyzz_to_affine(x1, y1, acc))
-    aff_store(&out[i], x1, y1);
-  else
-    aff_store_inf(&out[i]);
+  xyzz_store(&out[i], acc);
 }
 
-// out[i] = s_lo * lo[i*stride] + s_hi * hi[i*stride]
-__global__ void __launch_bounds__(256) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
-                                                     u32 stride, const uint8_t* __restrict__ s_lo_be,
-                                                     const uint8_t* __restrict__ s_hi_be, aff_mem* __restrict__ out,
-                                                     u32 n_lo, u32 n_hi) {
-  // out has max(n_lo, n_hi) entries; a missing side counts as infinity (vectorPointsAdd padding,
-  // go/bppp/util.go:279-293)
-  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+// Joint sparse form (Solinas) of the two fold scalars, computed once on the host: digit pairs
+// (d_lo, d_hi) in {0, +1, -1}^2, 4 bits per position (0 -> 0, +1 -> 1, -1 -> 3), at most 257
+// positions, about half of them non-zero.
+struct jsf_arg {
+  u32 w[34];
+  u32 len;
+};
+
+// out[i] = s_lo * lo[i*stride] + s_hi * hi[i*stride], one QUAD per output point.  Both scalars
+// are the same for every point (generator folding, go/bp/main.go:355-356,
+// go/bppp/docs_test.go:1325-1326; vectorPointMulOnScalar go/bp/util.go:177-183 with s_hi = 0),
+// so the whole grid follows one joint double-and-add chain without divergence: per digit one
+// quad-cooperative doubling (3 multiply stages) and, for a non-zero pair, one quad-cooperative
+// addition of +-P, +-Q, +-(P+Q) or +-(P-Q) (4 stages).  out has max(n_lo, n_hi) entries; a
+// missing side counts as infinity (vectorPointsAdd padding, go/bppp/util.go:279-293).
+__global__ void __launch_bounds__(256) k_fold_points_quad(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
+                                                          u32 stride, jsf_arg jsf, xyzz_mem* __restrict__ out, u32 n_lo,
+                                                          u32 n_hi) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = gid >> 2, role = gid & 3u;
   u32 n = n_lo > n_hi ? n_lo : n_hi;
-  if (i >= n) return;
+  if (i >= n) return;  // a quad leaves together
   fe x, y;
-  xyzz a, b, r;
-  xyzz_set_inf(a);
-  xyzz_set_inf(b);
-  u32 k[8];
-  if (i < n_lo && aff_load(x, y, &lo[(size_t)i * stride], false)) {
-    scalar_load_be(k, s_lo_be);
-    g1_scalar_mul(a, x, y, k);
+  xyzz P, Q, S, D, acc;
+  xyzz_set_inf(P);
+  xyzz_set_inf(Q);
+  if (i < n_lo && aff_load(x, y, &lo[(size_t)i * stride], false)) xyzz_from_affine(P, x, y);
+  if (i < n_hi && aff_load(x, y, &hi[(size_t)i * stride], false)) xyzz_from_affine(Q, x, y);
+  xyzz_add_quad(S, P, Q, role);
+  {
+    xyzz Qn = Q;
+    Qn.y = fe_neg(Q.y);
+    xyzz_add_quad(D, P, Qn, role);
   }
-  if (i < n_hi && aff_load(x, y, &hi[(size_t)i * stride], false)) {
-    scalar_load_be(k, s_hi_be);
-    g1_scalar_mul(b, x, y, k);
+  xyzz_set_inf(acc);
+  for (int j = (int)jsf.len - 1; j >= 0; j--) {
+    xyzz t;
+    xyzz_dbl_quad(t, acc, role);
+    acc = t;
+    u32 d = (jsf.w[j >> 3] >> ((j & 7) * 4)) & 15u;
+    if (d == 0) continue;
+    u32 d0 = d & 3u, d1 = d >> 2;
+    xyzz T;
+    bool neg;
+    if (d1 == 0) {
+      T = P;
+      neg = d0 == 3u;
+    } else if (d0 == 0) {
+      T = Q;
+      neg = d1 == 3u;
+    } else if (d0 == d1) {
+      T = S;
+      neg = d0 == 3u;
+    } else {
+      T = D;
+      neg = d0 == 3u;
+    }
+    if (neg) T.y = fe_neg(T.y);
+    xyzz_add_quad(t, acc, T, role);
+    acc = t;
   }
-  xyzz_add(r, a, b);
-  if (xyzz_to_affine(x, y, r))
-    aff_store(&out[i], x, y);
-  else
-    aff_store_inf(&out[i]);
+  if (role == 0) xyzz_store(&out[i], acc);
 }
 
 // ------------------------------------------------------------------ synthetic workload

@@ -140,6 +140,14 @@ int bn256_fr_dot(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t a_st
 int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n, const bn256_frvec* v,
                  size_t v_off, size_t v_stride, uint8_t out_xy_be[64]);
 
+/* Sum of k such view-MSMs as ONE device MSM (the segments are gathered into contiguous arrays
+ * first): vecCom / productCom / InnerProductH (go/bp/util.go:15-27,96-104) and the WNLA X and R
+ * commitments (go/bppp/docs_test.go:1296-1316) over resident vectors.  scale_be (array or NULL;
+ * entries may be NULL) multiplies segment i's scalars: <rho * n1, G0> without a scaled copy. */
+int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* stride,
+                       const size_t* n, const bn256_frvec* const* v, const size_t* v_off, const size_t* v_stride,
+                       const uint8_t* const* scale_be, uint8_t out_xy_be[64]);
+
 /* Host-side sum of k marshalled points (combination of per-GPU partial MSMs). */
 int bn256_g1_sum(const uint8_t* xy_be, size_t k, uint8_t out_xy_be[64]);
 

@@ -155,3 +155,31 @@ def test_large_dot_linearity(eng):
     c = eng.fr_fold(a, 0, n, a, 0, n, s, t)
     aa = eng.fr_dot(a, 0, 1, n, a, 0, 1, n)
     assert eng.fr_dot(a, 0, 1, n, c, 0, 1, n) == (s + t) * aa % N
+
+
+def test_fused_multi_segment_msm(eng, orc):
+    """WNLA X commitment shape: <l1,H0> + <l0,H1> + rho<n1,G0> + rho^-1<n0,G1> as one MSM."""
+    rng = random.Random(77)
+    nh, ng = 37, 20
+    H = eng.random_bases(0xA1, nh)
+    G = eng.random_bases(0xA2, ng)
+    l = eng.fr_random(0xA3, nh)
+    n = eng.fr_random(0xA4, ng)
+    Hp, Gp, lv, nv = H.download(), G.download(), l.download(), n.download()
+    ro = rng.randrange(1, N)
+    roinv = ref.finv(ro)
+    h0, h1, g0, g1 = (nh + 1) // 2, nh // 2, (ng + 1) // 2, ng // 2
+    segs = [(H, 0, 2, min(h0, h1), l, 1, 2), (H, 1, 2, h1, l, 0, 2),
+            (G, 0, 2, min(g0, g1), n, 1, 2, ro), (G, 1, 2, g1, n, 0, 2, roinv)]
+    got = eng.msm_fr_multi(segs)
+    pts, scs = [], []
+    for (pp, po, ps, cnt, sv, so, ss, *sc) in [(Hp, 0, 2, min(h0, h1), lv, 1, 2), (Hp, 1, 2, h1, lv, 0, 2),
+                                                (Gp, 0, 2, min(g0, g1), nv, 1, 2, ro), (Gp, 1, 2, g1, nv, 0, 2, roinv)]:
+        k = sc[0] if sc else 1
+        for i in range(cnt):
+            pts.append(pp[po + i * ps])
+            scs.append(sv[so + i * ss] * k % N)
+    exp = orc.msm(b"".join(pts), b"".join(x.to_bytes(32, "big") for x in scs))
+    assert got == exp
+    assert eng.msm_fr_multi([]) == bytes(64)
+    assert eng.msm_fr_multi([(H, 0, 1, 0, l, 0, 1)]) == bytes(64)
