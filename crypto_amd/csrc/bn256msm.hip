@@ -390,19 +390,15 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   for (int i = 0; i < 6; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   HIPCHK(hipEventElapsedTime(&ctx->last_ms[6], ctx->ev[0], ctx->ev[6]));
 
-  // Host tail: per set S = T + sum_k 2^k G_k (Horner), then sum_w 2^(c w) S_w (Horner).
+  // Host tail: sum_w 2^(c w) (T_w + sum_k 2^k G_{w,k}) as ONE Horner chain over bit positions
+  // j = c w + k: (nsets-1) c + q - 1 doublings in all instead of a chain per set plus a chain over sets.
   Pt total = infinity();
-  for (int set = (int)nsets - 1; set >= 0; set--) {
-    const u32* base = ctx->h_pack + (size_t)set * (q + 1) * 32;
-    Pt acc = infinity();
-    for (int k = (int)q - 1; k >= 0; k--) {
-      acc = dbl(acc);
-      acc = padd(acc, from_device_words(base + (size_t)(k + 1) * 32));
-    }
-    acc = padd(acc, from_device_words(base));
-    if (set != (int)nsets - 1)
-      for (int j = 0; j < c; j++) total = dbl(total);
-    total = padd(total, acc);
+  for (int j = ((int)nsets - 1) * c + (int)q - 1; j >= 0; j--) {
+    total = dbl(total);
+    const int w = j / c, k = j % c;
+    const u32* base = ctx->h_pack + (size_t)w * (q + 1) * 32;
+    if (k < (int)q) total = padd(total, from_device_words(base + (size_t)(k + 1) * 32));
+    if (k == 0) total = padd(total, from_device_words(base));
   }
   *result = total;
   return BN256_OK;

@@ -71,34 +71,40 @@ inline Fp sub(const Fp& a, const Fp& b) {
   }
   return r;
 }
-// SOS Montgomery product: full 512-bit product, then word-by-word reduction.
+// CIOS Montgomery product, fully unrolled (p's top limb is >= 2^63, so the extra carry word stays).
 inline Fp mul(const Fp& a, const Fp& b) {
-  uint64_t t[9] = {0};
-  for (int i = 0; i < 4; i++) {
-    uint64_t c = 0;
-    for (int j = 0; j < 4; j++) {
-      u128 cur = (u128)a.l[i] * b.l[j] + t[i + j] + c;
-      t[i + j] = (uint64_t)cur;
-      c = (uint64_t)(cur >> 64);
-    }
-    t[i + 4] = c;
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#define HOSTG1_ROUND(bi)                                      \
+  {                                                           \
+    u128 cur = (u128)a.l[0] * (bi) + t0;                      \
+    uint64_t u0 = (uint64_t)cur;                              \
+    cur = (u128)a.l[1] * (bi) + t1 + (uint64_t)(cur >> 64);   \
+    uint64_t u1 = (uint64_t)cur;                              \
+    cur = (u128)a.l[2] * (bi) + t2 + (uint64_t)(cur >> 64);   \
+    uint64_t u2 = (uint64_t)cur;                              \
+    cur = (u128)a.l[3] * (bi) + t3 + (uint64_t)(cur >> 64);   \
+    uint64_t u3 = (uint64_t)cur;                              \
+    cur = (u128)t4 + (uint64_t)(cur >> 64);                   \
+    uint64_t u4 = (uint64_t)cur, u5 = (uint64_t)(cur >> 64);  \
+    uint64_t m = u0 * kNInv;                                  \
+    cur = (u128)m * kP[0] + u0;                               \
+    cur = (u128)m * kP[1] + u1 + (uint64_t)(cur >> 64);       \
+    t0 = (uint64_t)cur;                                       \
+    cur = (u128)m * kP[2] + u2 + (uint64_t)(cur >> 64);       \
+    t1 = (uint64_t)cur;                                       \
+    cur = (u128)m * kP[3] + u3 + (uint64_t)(cur >> 64);       \
+    t2 = (uint64_t)cur;                                       \
+    cur = (u128)u4 + (uint64_t)(cur >> 64);                   \
+    t3 = (uint64_t)cur;                                       \
+    t4 = u5 + (uint64_t)(cur >> 64);                          \
   }
-  for (int i = 0; i < 4; i++) {
-    uint64_t m = t[i] * kNInv;
-    uint64_t c = 0;
-    for (int j = 0; j < 4; j++) {
-      u128 cur = (u128)m * kP[j] + t[i + j] + c;
-      t[i + j] = (uint64_t)cur;
-      c = (uint64_t)(cur >> 64);
-    }
-    for (int k = i + 4; c && k < 9; k++) {
-      u128 cur = (u128)t[k] + c;
-      t[k] = (uint64_t)cur;
-      c = (uint64_t)(cur >> 64);
-    }
-  }
-  Fp r = {{t[4], t[5], t[6], t[7]}};
-  if (t[8] || raw_geq_p(r.l)) {
+  HOSTG1_ROUND(b.l[0])
+  HOSTG1_ROUND(b.l[1])
+  HOSTG1_ROUND(b.l[2])
+  HOSTG1_ROUND(b.l[3])
+#undef HOSTG1_ROUND
+  Fp r = {{t0, t1, t2, t3}};
+  if (t4 || raw_geq_p(r.l)) {
     u128 br = 0;
     for (int i = 0; i < 4; i++) {
       u128 d = (u128)r.l[i] - kP[i] - br;
