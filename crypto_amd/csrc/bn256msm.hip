@@ -453,10 +453,49 @@ extern "C" int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases*
                                        uint8_t out_xy_be[64]) {
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
   HIPCHK(hipSetDevice(ctx->device));
+  // Small or table-less segments are gathered into one contiguous (points, scalars) pair and run
+  // as ONE device MSM (one sort, one bucket reduction, one host tail); segments over large
+  // fixed-base tables keep their own pipeline so that the tables are used.
+  size_t total_n = 0;
+  bool big_table = false;
+  for (int i = 0; i < k; i++) {
+    if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
+    int rc = range_check(b[i], off[i], n[i], stride ? stride[i] : 1);
+    if (rc) return rc;
+    total_n += n[i];
+    if (b[i]->levels > 1 && n[i] >= (1u << 15)) big_table = true;
+  }
+  if (k > 1 && !big_table && total_n > 0 && total_n < (1ull << 31)) {
+    int rc;
+    if ((rc = ws_reserve(ctx, WS_GATHER, total_n * sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, total_n * 32)))
+      return rc;
+    aff_mem* pts = (aff_mem*)ctx->ws[WS_GATHER];
+    uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
+    size_t pos = 0;
+    fr_arg none;
+    memset(&none, 0, sizeof none);
+    for (int i = 0; i < k; i++) {
+      if (!n[i]) continue;
+      HIPCHK(hipMemcpyAsync(sc + pos * 32, scalars_be[i], n[i] * 32, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(n[i], 256)), dim3(256), 0, ctx->stream,
+                         (const uint4*)(b[i]->d + off[i]), (u32)(stride ? stride[i] : 1), (uint4*)(pts + pos),
+                         (const uint8_t*)nullptr, 1u, none, 0u, (uint8_t*)nullptr, (u32)n[i]);
+      pos += n[i];
+    }
+    bn256_bases tmp;
+    tmp.d = pts;
+    tmp.n = total_n;
+    tmp.levels = 1;
+    tmp.c = 0;
+    hostg1::Pt r;
+    rc = msm_core(ctx, &tmp, 0, 1, total_n, sc, &r);
+    if (rc) return rc;
+    hostg1::marshal(out_xy_be, r);
+    return BN256_OK;
+  }
   hostg1::Pt total = hostg1::infinity();
   float ms[7] = {0};
   for (int i = 0; i < k; i++) {
-    if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
     hostg1::Pt r;
     int rc = msm_host_scalars(ctx, b[i], off[i], stride ? stride[i] : 1, n[i], scalars_be[i], &r);
     if (rc) return rc;

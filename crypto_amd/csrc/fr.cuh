@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256) k_gather_segment(const uint4* __restrict_
   dp[1] = b;
   dp[2] = c;
   dp[3] = d;
+  if (!src_sc) return;  // points only: the caller supplies the scalars itself
   fr x = fr_load_be(src_sc + (size_t)i * sc_stride * 32);
   if (has_scale) x = fr_mont(x, fr_to_mont(fr_from_arg(scale)));
   fr_store_be(dst_sc + (size_t)i * 32, x);
