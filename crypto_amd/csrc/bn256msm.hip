@@ -34,7 +34,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -44,6 +44,7 @@ struct bn256_ctx {
   hipEvent_t ev[8];
   float last_ms[7];
   int tune_c, tune_k;
+  size_t msm_chunk;  // 0 = MSM_CHUNK; BN256_MSM_CHUNK_LOG2 in the environment overrides (experiments)
   int lds_attr_set;
   u32* h_pack;      // pinned
   size_t h_pack_cap;
@@ -96,6 +97,10 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   if (!ctx) return BN256_ENOMEM;
   memset(ctx, 0, sizeof *ctx);
   ctx->device = device;
+  if (const char* e = getenv("BN256_MSM_CHUNK_LOG2")) {
+    int lg = atoi(e);
+    if (lg >= 10 && lg <= 30) ctx->msm_chunk = (size_t)1 << lg;
+  }
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc(&ctx->d_err, 256));
@@ -272,8 +277,13 @@ extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t
 }
 
 // ---------------------------------------------------------------------------- MSM core
-// Runs the device pipeline for one contiguous range with device-resident scalars and returns
-// the XYZZ sum as a host point.
+// Fixed-base calls above this many points run as several passes over sub-ranges whose bucket
+// arrays are added before the reduction: at 2^22+ points the gathers range over a 4-16 GiB table
+// and both the scatter and the accumulation slow down per entry ("large n").
+#define MSM_CHUNK ((size_t)1 << 21)
+
+// Runs the device pipeline for one range of a bases handle (view: off, stride) with
+// device-resident scalars (view: sc_stride) and returns the XYZZ sum as a host point.
 static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
                     const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1) {
   using namespace hostg1;
@@ -287,12 +297,13 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   const u32 nb = 1u << (c - 1);
   const u32 nsets = precomp ? 1u : (u32)W;
   const size_t nbt = (size_t)nb * nsets;
-  const unsigned long long entries = (unsigned long long)n * W;
-  if (entries >= (1ull << 31) || (unsigned long long)b->n * b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
+  if ((unsigned long long)b->n * b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
   const u32 q = (u32)(c - 1);
-
-  u32 K = ctx->tune_k ? (u32)ctx->tune_k : (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(16, entries / 262144));
-  const size_t T = (size_t)((entries + K - 1) / K);
+  const size_t chunk = ctx->msm_chunk ? ctx->msm_chunk : MSM_CHUNK;
+  const size_t nchunks = (precomp && n > chunk) ? (n + chunk - 1) / chunk : 1;
+  const size_t nmax = nchunks > 1 ? chunk : n;  // largest pass
+  const unsigned long long entries_max = (unsigned long long)nmax * W;
+  if (entries_max >= (1ull << 31)) return BN256_ETOOLARGE;
   const u32 nscan = nblocks(nbt + 1, SCAN_TILE);
   const size_t npack = (size_t)nsets * (q + 1);
 
@@ -300,29 +311,36 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   // LDS-staged sort when one set's histogram fits the 160 KB LDS (nb <= 2^15)
   const bool use_lds = (size_t)nb * 4 <= 128 * 1024;
   const size_t lds_bytes = (size_t)nb * 4;
-  u32 ntiles = 1, tile_len = (u32)n;
+  const u32 want_tiles = std::max<u32>(1, 256 / nsets);
   if (use_lds) {
-    u32 want = std::max<u32>(1, 256 / nsets);
-    ntiles = (u32)std::min<size_t>(want, (n + 1023) / 1024);
-    if (ntiles < 1) ntiles = 1;
-    tile_len = (u32)((n + ntiles - 1) / ntiles);
-    ntiles = (u32)((n + tile_len - 1) / tile_len);
-    if ((rc = ws_reserve(ctx, WS_RANK, (size_t)nsets * ntiles * nb * 4))) return rc;  // per-tile histograms
+    if ((rc = ws_reserve(ctx, WS_RANK, (size_t)nsets * want_tiles * nb * 4))) return rc;  // per-tile histograms
     if (lds_bytes > 48 * 1024 && !ctx->lds_attr_set) {
       HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
       ctx->lds_attr_set = 1;
     }
   } else {
-    if ((rc = ws_reserve(ctx, WS_RANK, entries * 4))) return rc;
+    if ((rc = ws_reserve(ctx, WS_RANK, entries_max * 4))) return rc;
   }
-  if ((rc = ws_reserve(ctx, WS_SVAL, entries * 4))) return rc;
+  // chunk length K of the accumulation kernel and its thread count for a pass of m points
+  auto pick_k = [&](size_t m) -> u32 {
+    unsigned long long e = (unsigned long long)m * W;
+    return ctx->tune_k ? (u32)ctx->tune_k : (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(16, e / 262144));
+  };
+  auto threads_for = [&](size_t m) -> size_t {
+    unsigned long long e = (unsigned long long)m * W;
+    u32 K = pick_k(m);
+    return (size_t)((e + K - 1) / K);
+  };
+  const size_t Tmax = std::max(threads_for(nmax), threads_for(n - (nchunks - 1) * nmax));
+  if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
   if ((rc = ws_reserve(ctx, WS_COUNTS, (nbt + 1) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BLOCKSUM, (size_t)(nscan + 1) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BUCKETS, nbt * sizeof(xyzz_mem)))) return rc;
-  if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * T * sizeof(xyzz_mem)))) return rc;
+  if (nchunks > 1 && (rc = ws_reserve(ctx, WS_BUCKETS2, nbt * sizeof(xyzz_mem)))) return rc;
+  if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * Tmax * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_PACK, npack * 32 * 4))) return rc;
   if (npack * 32 * 4 > ctx->h_pack_cap) return BN256_EINVAL;
 
@@ -333,62 +351,100 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   u32* sval = (u32*)ctx->ws[WS_SVAL];
   u32* blocksum = (u32*)ctx->ws[WS_BLOCKSUM];
   xyzz_mem* buckets = (xyzz_mem*)ctx->ws[WS_BUCKETS];
+  xyzz_mem* sum_buckets = nchunks > 1 ? (xyzz_mem*)ctx->ws[WS_BUCKETS2] : buckets;
   xyzz_mem* partials = (xyzz_mem*)ctx->ws[WS_PARTIALS];
   u32* d_pack = (u32*)ctx->ws[WS_PACK];
   u32* heavy_count = ctx->d_err + 16;
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
 
-  HIPCHK(hipEventRecord(ctx->ev[0], s));
-  HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
-  if (use_lds) {
-    hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
-                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
-                       (const u32*)nullptr, (u32*)nullptr);
-    HIPCHK(hipEventRecord(ctx->ev[1], s));
-    hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
-  } else {
-    HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
-    hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank, (const u32*)nullptr,
-                       (u32*)nullptr);
-    HIPCHK(hipEventRecord(ctx->ev[1], s));
+  for (size_t ch = 0; ch < nchunks; ch++) {
+    const size_t n_ch = std::min(nmax, n - ch * nmax);
+    const size_t off_ch = off + ch * nmax * stride;
+    const uint8_t* sc_ch = d_scalars + ch * nmax * sc_stride * 32;
+    const unsigned long long entries = (unsigned long long)n_ch * W;
+    const u32 K = pick_k(n_ch);
+    const size_t T = threads_for(n_ch);
+    if (2 * T * sizeof(xyzz_mem) > ctx->cap[WS_PARTIALS] || entries > entries_max) return BN256_EINVAL;
+    u32 ntiles = 1, tile_len = (u32)n_ch;
+    if (use_lds) {
+      ntiles = (u32)std::min<size_t>(want_tiles, (n_ch + 1023) / 1024);
+      if (ntiles < 1) ntiles = 1;
+      tile_len = (u32)((n_ch + ntiles - 1) / ntiles);
+      ntiles = (u32)((n_ch + tile_len - 1) / tile_len);
+    }
+
+    HIPCHK(hipEventRecord(ctx->ev[0], s));
+    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
+    if (use_lds) {
+      hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
+                         (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
+                         (const u32*)nullptr, (u32*)nullptr);
+      HIPCHK(hipEventRecord(ctx->ev[1], s));
+      hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
+    } else {
+      HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
+      hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
+                         (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank,
+                         (const u32*)nullptr, (u32*)nullptr);
+      HIPCHK(hipEventRecord(ctx->ev[1], s));
+    }
+    // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
+    hipLaunchKernelGGL(k_scan1, dim3(nscan), dim3(SCAN_BLOCK), 0, s, (const u32*)counts, offsets, (u32)(nbt + 1), blocksum);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, blocksum, nscan, blocksum + nscan);
+    hipLaunchKernelGGL(k_scan3, dim3(nscan), dim3(SCAN_BLOCK), 0, s, offsets, (u32)(nbt + 1), (const u32*)blocksum);
+    HIPCHK(hipEventRecord(ctx->ev[2], s));
+    if (use_lds) {
+      hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
+                         (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
+                         (const u32*)offsets, sval);
+    } else {
+      hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
+                         (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank,
+                         (const u32*)offsets, sval);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], s));
+    hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
+                       (const u32*)offsets, (u32)nbt, K, buckets, partials);
+    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
+                       (const xyzz_mem*)partials, heavy_count, heavy_list);
+    hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
+                       (const u32*)heavy_count, (const u32*)heavy_list);
+    if (nchunks > 1) {
+      if (ch == 0)
+        HIPCHK(hipMemcpyAsync(sum_buckets, buckets, nbt * sizeof(xyzz_mem), hipMemcpyDeviceToDevice, s));
+      else
+        hipLaunchKernelGGL(k_add_buckets, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, sum_buckets,
+                           (const xyzz_mem*)buckets, (u32)nbt);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[5], s));
+    if (ch + 1 < nchunks) {  // per-pass phase times; the last pass is read after the reduction
+      HIPCHK(hipStreamSynchronize(s));
+      for (int i = 0; i < 5; i++) {
+        float ms;
+        HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        ctx->last_ms[i] += ms;
+        ctx->last_ms[6] += ms;
+      }
+    }
   }
-  // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
-  hipLaunchKernelGGL(k_scan1, dim3(nscan), dim3(SCAN_BLOCK), 0, s, (const u32*)counts, offsets, (u32)(nbt + 1), blocksum);
-  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, blocksum, nscan, blocksum + nscan);
-  hipLaunchKernelGGL(k_scan3, dim3(nscan), dim3(SCAN_BLOCK), 0, s, offsets, (u32)(nbt + 1), (const u32*)blocksum);
-  HIPCHK(hipEventRecord(ctx->ev[2], s));
-  if (use_lds) {
-    hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, d_scalars, (u32)n, (u32)c,
-                       (u32)W, nb, (u32)precomp, (u32)off, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
-                       (const u32*)offsets, sval);
-  } else {
-    hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, (u32)c, (u32)W, nb,
-                       (u32)precomp, (u32)off, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank, (const u32*)offsets,
-                       sval);
-  }
-  HIPCHK(hipEventRecord(ctx->ev[3], s));
-  hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                     (const u32*)offsets, (u32)nbt, K, buckets, partials);
-  HIPCHK(hipEventRecord(ctx->ev[4], s));
-  hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
-                     (const xyzz_mem*)partials, heavy_count, heavy_list);
-  hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
-                     (const u32*)heavy_count, (const u32*)heavy_list);
-  HIPCHK(hipEventRecord(ctx->ev[5], s));
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
-    hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, buckets, nsets, nb, l);
+    hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, sum_buckets, nsets, nb, l);
   }
-  hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)buckets, nsets, nb, q,
+  hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)sum_buckets, nsets, nb, q,
                      d_pack);
   HIPCHK(hipEventRecord(ctx->ev[6], s));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, npack * 32 * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  for (int i = 0; i < 6; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
-  HIPCHK(hipEventElapsedTime(&ctx->last_ms[6], ctx->ev[0], ctx->ev[6]));
+  for (int i = 0; i < 6; i++) {
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+    ctx->last_ms[i] += ms;
+    ctx->last_ms[6] += ms;
+  }
 
   // Host tail: sum_w 2^(c w) (T_w + sum_k 2^k G_{w,k}) as ONE Horner chain over bit positions
   // j = c w + k: (nsets-1) c + q - 1 doublings in all instead of a chain per set plus a chain over sets.

@@ -442,6 +442,19 @@ __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32
 }
 
 // Canonical, non-Montgomery X,Y,ZZ,ZZZ (8 x u32 LE each) of T and G_k for the host tail.
+// total[b] += part[b], one quad per bucket (sub-range passes of one large MSM)
+__global__ void __launch_bounds__(64) k_add_buckets(xyzz_mem* __restrict__ total, const xyzz_mem* __restrict__ part,
+                                                    u32 nbt) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = gid >> 2, role = gid & 3u;
+  if (i >= nbt) return;
+  xyzz a, b, r;
+  xyzz_load(a, &total[i]);
+  xyzz_load(b, &part[i]);
+  xyzz_add_quad(r, a, b, role);
+  if (role == 0) xyzz_store(&total[i], r);
+}
+
 __global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb,
                                                      u32 q, u32* __restrict__ out) {
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;

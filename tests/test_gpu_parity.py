@@ -246,3 +246,23 @@ def test_two_contexts_are_independent(orc):
     finally:
         e1.close()
         e2.close()
+
+
+def test_sub_range_passes_match_single_pass(orc, monkeypatch):
+    """Large fixed-base calls run as several passes whose bucket arrays are added before the
+    reduction (MSM_CHUNK); forced here at 2^10 points per pass, ragged last pass included."""
+    import crypto_amd
+    monkeypatch.setenv("BN256_MSM_CHUNK_LOG2", "10")
+    e = crypto_amd.Engine(0)
+    try:
+        for n in (1024, 1025, 5000):
+            bases = e.random_bases(0xC0 + n, n, flags=crypto_amd.PRECOMPUTE)
+            v = e.fr_random(0xD0 + n, n)
+            exp = orc.msm(orc.synth_bases(0xC0 + n, n), orc.synth_scalars(0xD0 + n, n))
+            assert e.msm_fr(bases, 0, 1, n, v) == exp
+            # a sub-range that starts inside a pass
+            exp2 = orc.msm(orc.synth_bases(0xC0 + n, n)[64 * 7:], orc.synth_scalars(0xD0 + n, n)[32 * 3:32 * (n - 4)])
+            assert e.msm_fr(bases, 7, 1, n - 7, v, 3, 1) == exp2
+            bases.free()
+    finally:
+        e.close()
