@@ -679,6 +679,48 @@ extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff
   return BN256_OK;
 }
 
+extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const uint8_t h_xy_be[64],
+                               const uint8_t* a_be, const uint8_t* b_be, size_t n, bn256_bases** out) {
+  if (!ctx || !g_xy_be || !h_xy_be || !out || ((!a_be || !b_be) && n)) return BN256_EINVAL;
+  *out = nullptr;
+  if (n >= (1ull << 29)) return BN256_ETOOLARGE;
+  HIPCHK(hipSetDevice(ctx->device));
+  uint8_t gh[128];
+  memcpy(gh, g_xy_be, 64);
+  memcpy(gh + 64, h_xy_be, 64);
+  bn256_bases* pts = nullptr;
+  int rc = bn256_bases_upload(ctx, gh, 2, 0, &pts);  // validates both points
+  if (rc) return rc;
+  bn256_bases* r = bases_alloc(n, 1, 0, &rc);
+  if (!r) { bn256_bases_free(ctx, pts); return rc; }
+  if (n) {
+    xyzz_mem* xs = nullptr;
+    if ((rc = xyzz_scratch(ctx, n, &xs)) || (rc = ws_reserve(ctx, WS_SCALARS, 2 * n * 32))) {
+      bn256_bases_free(ctx, pts);
+      bn256_bases_free(ctx, r);
+      return rc;
+    }
+    uint8_t* ds = (uint8_t*)ctx->ws[WS_SCALARS];
+    hipError_t e = hipMemcpyAsync(ds, a_be, n * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ds + n * 32, b_be, n * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_com_batch_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)pts->d,
+                         (const uint8_t*)ds, (const uint8_t*)(ds + n * 32), xs, (u32)n);
+      normalize_into(ctx, xs, r->d, n);
+      e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) {
+      ctx_note_hip(e, __LINE__);
+      bn256_bases_free(ctx, pts);
+      bn256_bases_free(ctx, r);
+      return BN256_EHIP;
+    }
+  }
+  bn256_bases_free(ctx, pts);
+  *out = r;
+  return BN256_OK;
+}
+
 extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
                            size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32],
                            const uint8_t s_hi_be[32], bn256_bases** out) {

@@ -701,6 +701,40 @@ __global__ void __launch_bounds__(256) k_fold_points_quad(const aff_mem* __restr
   if (role == 0) xyzz_store(&out[i], acc);
 }
 
+// out[i] = a_i * g + b_i * h: n independent 2-term Pedersen commitments with per-output scalars --
+// com() of go/bp/util.go:92-94 batched, and X[i] = x0[i]*GenH + x1[i]*GenG of go/ve-ca/main.go:37-40.
+// One quad per output, joint binary double-and-add over {g, h, g+h}; gh holds g, h (affine).
+__global__ void __launch_bounds__(256) k_com_batch_quad(const aff_mem* __restrict__ gh, const uint8_t* __restrict__ a_be,
+                                                        const uint8_t* __restrict__ b_be, xyzz_mem* __restrict__ out,
+                                                        u32 n) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = gid >> 2, role = gid & 3u;
+  if (i >= n) return;
+  fe x, y;
+  xyzz P, Q, S, acc;
+  xyzz_set_inf(P);
+  xyzz_set_inf(Q);
+  if (aff_load(x, y, &gh[0], false)) xyzz_from_affine(P, x, y);
+  if (aff_load(x, y, &gh[1], false)) xyzz_from_affine(Q, x, y);
+  xyzz_add_quad(S, P, Q, role);
+  u32 ka[8], kb[8];
+  scalar_load_be(ka, a_be + (size_t)i * 32);  // any 256-bit integer works: n * P = infinity
+  scalar_load_be(kb, b_be + (size_t)i * 32);
+  xyzz_set_inf(acc);
+  for (int bit = 255; bit >= 0; bit--) {
+    xyzz t;
+    xyzz_dbl_quad(t, acc, role);
+    acc = t;
+    u32 da = (sel8(ka, (u32)bit >> 5) >> (bit & 31)) & 1u;
+    u32 db = (sel8(kb, (u32)bit >> 5) >> (bit & 31)) & 1u;
+    if ((da | db) == 0) continue;
+    xyzz T = (da & db) ? S : (da ? P : Q);
+    xyzz_add_quad(t, acc, T, role);
+    acc = t;
+  }
+  if (role == 0) xyzz_store(&out[i], acc);
+}
+
 // ------------------------------------------------------------------ synthetic workload
 __device__ __forceinline__ u64 mix64(u64 z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -260,6 +260,14 @@ class Engine:
         self._chk(self.lib.bn256_msm_fr_multi(self.ctx, k, hs, offs, strides, ns, vs, voffs, vstrides, scales, out))
         return out.raw
 
+    def com_batch(self, g: bytes, h: bytes, a: Sequence[int], b: Sequence[int]) -> Bases:
+        """[a_i*g + b_i*h]: com() of go/bp/util.go:92-94 over independent pairs (go/ve-ca/main.go:37-40)."""
+        if len(a) != len(b):
+            raise ValueError("invalid length")
+        hd = C.c_void_p()
+        self._chk(self.lib.bn256_com_batch(self.ctx, g, h, scalars_to_bytes(a), scalars_to_bytes(b), len(a), C.byref(hd)))
+        return Bases(self, hd)
+
     def g1_sum(self, pts: Sequence[bytes]) -> bytes:
         out = C.create_string_buffer(64)
         self._chk(self.lib.bn256_g1_sum(b"".join(pts), len(pts), out))

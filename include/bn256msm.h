@@ -91,6 +91,12 @@ int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256
                size_t stride, size_t n, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
                bn256_bases** out);
 
+/* out[i] = a_i * g + b_i * h for i < n: com() (go/bp/util.go:92-94) batched over independent
+ * scalar pairs -- the k = 128 commitments X[i] = x0[i]*GenH + x1[i]*GenG of go/ve-ca/main.go:37-40
+ * and the alpha0*GenH + alpha1*GenG part of its Verify (:102-109).  g, h: Marshal() bytes. */
+int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const uint8_t h_xy_be[64], const uint8_t* a_be,
+                    const uint8_t* b_be, size_t n, bn256_bases** out);
+
 /* Ragged form of bn256_fold: out has max(n_lo, n_hi) points and a missing side counts as
  * infinity -- vectorPointsAdd's padding (go/bppp/util.go:279-293) for odd-length WNLA rounds. */
 int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,

@@ -266,3 +266,23 @@ def test_sub_range_passes_match_single_pass(orc, monkeypatch):
             bases.free()
     finally:
         e.close()
+
+
+def test_com_batch_matches_oracle(eng):
+    """k = 128 two-term commitments (go/ve-ca/main.go:37-40 shape) against com(), go/bp/util.go:92-94."""
+    import random
+    rng = random.Random(3)
+    g, h = ref.base_mul(rng.randrange(1, N_ORDER)), ref.base_mul(rng.randrange(1, N_ORDER))
+    a = [rng.randrange(N_ORDER) for _ in range(128)]
+    b = [rng.randrange(N_ORDER) for _ in range(128)]
+    a[:6] = [0, 1, 0, N_ORDER - 1, 2**256 - 1, 5]
+    b[:6] = [0, 0, 1, 1, 7, N_ORDER - 5]
+    got = eng.com_batch(ref.marshal(g), ref.marshal(h), a, b).download()
+    exp = [ref.marshal(ref.com(g, h, x, y)) for x, y in zip(a, b)]
+    assert got == exp
+    # h = g and h = -g exercise the doubling / cancellation paths of g + h
+    got = eng.com_batch(ref.marshal(g), ref.marshal(g), a[:8], b[:8]).download()
+    assert got == [ref.marshal(ref.mul((x + y) % N_ORDER, g)) for x, y in zip(a[:8], b[:8])]
+    got = eng.com_batch(ref.marshal(g), ref.marshal(ref.neg(g)), a[:8], b[:8]).download()
+    assert got == [ref.marshal(ref.mul((x - y) % N_ORDER, g)) for x, y in zip(a[:8], b[:8])]
+    assert eng.com_batch(ref.marshal(g), ref.marshal(h), [], []).download() == []
