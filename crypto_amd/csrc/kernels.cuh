@@ -169,6 +169,110 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ two-pass sort (fixed-base, c = 16)
+// The single-pass scatter above writes every 4-byte entry to its own place in a 64 MiB array:
+// one 32-byte HBM sector per entry (PMC WRITE_SIZE 526 MB for 67 MB of entries).  With a table
+// (one set of nb = 2^15 buckets) the sort is split so that every store lands in a small number
+// of open lines that the L2 can merge:
+//   pass A  k_part<0/1>      tile of scalars -> G = nb/B groups (high key bits): per-tile group
+//                            counts, scan, then records ((w,i,sign) << LB | low key bits) written
+//                            group-major / tile-major; 512 open lines per tile
+//   pass B  k_group_count    group g, sub-part s (1/S of the tiles): LDS histogram of the B = 64 low
+//           k_group_place    keys -> scan over (bucket, sub-part) -> final positions; 64 open
+//                            lines per workgroup.  Also emits offsets[] for k_accumulate.
+// A group that holds nearly all entries (skewed scalars) is still spread over S workgroups.
+#define SORT2_LB 6u    // log2 buckets per group
+#define SORT2_S 32u    // sub-parts per group
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 tile_len,
+                                               u32 sc_stride, u32 G, u32 ibits, u32* __restrict__ ghist,
+                                               const u32* __restrict__ gbase, u32* __restrict__ rec) {
+  extern __shared__ u32 lds[];  // SCATTER: cursor[G]; else per-wave histograms [16][G]
+  const u32 tile = blockIdx.x, ntiles = gridDim.x, wave = threadIdx.x >> 6;
+  if (!SCATTER) {
+    for (u32 j = threadIdx.x; j < 16 * G; j += blockDim.x) lds[j] = 0;
+  } else {
+    for (u32 j = threadIdx.x; j < G; j += blockDim.x) lds[j] = gbase[(size_t)j * ntiles + tile];
+  }
+  __syncthreads();
+  u32 lo = tile * tile_len;
+  u32 hi = (n - lo > tile_len) ? lo + tile_len : n;
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 k[8];
+    scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
+    bool neg = scalar_reduce_signed(k);
+    u32 carry = 0;
+    for (u32 w = 0; w < W; w++) {
+      u32 mag, sign;
+      recode_digit(k, neg, w, c, carry, mag, sign);
+      if (mag == 0) continue;
+      u32 key = mag - 1, grp = key >> SORT2_LB;
+      if (!SCATTER) {
+        atomicAdd(&lds[wave * G + grp], 1u);
+      } else {
+        u32 pos = atomicAdd(&lds[grp], 1u);
+        rec[pos] = (((((w << ibits) | i) << 1) | sign) << SORT2_LB) | (key & ((1u << SORT2_LB) - 1u));
+      }
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < G; j += blockDim.x) {
+      u32 t = 0;
+#pragma unroll
+      for (u32 v = 0; v < 16; v++) t += lds[v * G + j];
+      ghist[(size_t)j * ntiles + tile] = t;
+    }
+    if (tile == 0 && threadIdx.x == 0) ghist[(size_t)G * ntiles] = 0;  // sentinel: scan yields the total
+  }
+}
+
+// gbase: exclusive scan of ghist (G*ntiles + 1 entries).  Block (g, s) owns the records of tiles
+// [s*TS, (s+1)*TS) of group g, a contiguous range of rec[].
+__global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ gbase,
+                                                     u32 ntiles, u32 TS, u32 nb, u32* __restrict__ subhist) {
+  __shared__ u32 h[4][1u << SORT2_LB];
+  const u32 B = 1u << SORT2_LB;
+  const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S, wave = threadIdx.x >> 6;
+  h[threadIdx.x >> SORT2_LB][threadIdx.x & (B - 1)] = 0;  // 256 threads == 4 * 64 counters
+  __syncthreads();
+  const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
+  for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&h[wave][rec[e] & (B - 1)], 1u);
+  __syncthreads();
+  if (threadIdx.x < B) {
+    u32 b = threadIdx.x;
+    subhist[((size_t)g * B + b) * SORT2_S + sp] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) subhist[(size_t)nb * SORT2_S] = 0;  // sentinel
+}
+
+// subscan: exclusive scan of subhist (nb*S + 1 entries) = first position of (bucket, sub-part).
+__global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec, const u32* __restrict__ gbase,
+                                                     const u32* __restrict__ subscan, u32 ntiles, u32 TS, u32 nb,
+                                                     u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
+                                                     u32* __restrict__ offsets, u32* __restrict__ sval) {
+  __shared__ u32 cur[1u << SORT2_LB];
+  const u32 B = 1u << SORT2_LB;
+  const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
+  if (threadIdx.x < B) {
+    u32 b = threadIdx.x;
+    u32 p = subscan[((size_t)g * B + b) * SORT2_S + sp];
+    cur[b] = p;
+    if (sp == 0) offsets[g * B + b] = p;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nb] = subscan[(size_t)nb * SORT2_S];
+  __syncthreads();
+  const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
+  for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+    u32 r = rec[e];
+    u32 pos = atomicAdd(&cur[r & (B - 1)], 1u);
+    u32 v = r >> SORT2_LB;
+    u32 idx = v >> 1;
+    u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & ((1u << ibits) - 1u)) * pt_stride;
+    sval[pos] = (tidx << 1) | (v & 1u);
+  }
+}
+
 // thread per (set, bucket): exclusive prefix of hist over tiles (in place) and the bucket total
 __global__ void __launch_bounds__(256) k_tile_scan(u32* __restrict__ hist, u32 nsets, u32 ntiles, u32 nb,
                                                    u32* __restrict__ totals) {

@@ -286,3 +286,36 @@ def test_com_batch_matches_oracle(eng):
     got = eng.com_batch(ref.marshal(g), ref.marshal(ref.neg(g)), a[:8], b[:8]).download()
     assert got == [ref.marshal(ref.mul((x - y) % N_ORDER, g)) for x, y in zip(a[:8], b[:8])]
     assert eng.com_batch(ref.marshal(g), ref.marshal(h), [], []).download() == []
+
+
+def test_two_pass_sort_matches_single_pass(monkeypatch):
+    """The two-pass sort (>= 2^18 points with a table) against the single-pass sort on the same
+    inputs: uniform, Bulletproofs-like skew (one group holds nearly every entry), a ragged
+    chunked call whose last pass falls back, and one that does not."""
+    import numpy as np
+    import torch
+    import crypto_amd
+    monkeypatch.setenv("BN256_SORT1", "1")
+    e1 = crypto_amd.Engine(0)
+    monkeypatch.delenv("BN256_SORT1")
+    e2 = crypto_amd.Engine(0)
+    try:
+        for n in (1 << 18, (1 << 18) + 12345, (1 << 21) + 5000, (1 << 21) + 300000):
+            b1 = e1.random_bases(0xE0, n, flags=crypto_amd.PRECOMPUTE)
+            b2 = e2.random_bases(0xE0, n, flags=crypto_amd.PRECOMPUTE)
+            v1, v2 = e1.fr_random(0xE1, n), e2.fr_random(0xE1, n)
+            assert e1.msm_fr(b1, 0, 1, n, v1) == e2.msm_fr(b2, 0, 1, n, v2)
+            if n == 1 << 18:
+                bits = np.random.default_rng(1).integers(0, 2, size=n // 2, dtype=np.uint8)
+                arr = np.zeros((n, 32), dtype=np.uint8)
+                arr[: n // 2, 31] = bits
+                arr[n // 2:][bits == 0] = np.frombuffer((N_ORDER - 1).to_bytes(32, "big"), dtype=np.uint8)
+                raw = arr.tobytes()
+                s1, s2 = e1.fr_upload(raw), e2.fr_upload(raw)
+                r1 = e1.msm_fr(b1, 0, 1, n, s1)
+                assert r1 == e2.msm_fr(b2, 0, 1, n, s2) and r1 != INF
+            b1.free()
+            b2.free()
+    finally:
+        e1.close()
+        e2.close()
