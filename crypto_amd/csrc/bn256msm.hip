@@ -34,7 +34,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_GBASE, WS_SUBHIST, WS_SUBSCAN, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_GBASE, WS_SUBHIST, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -46,7 +46,6 @@ struct bn256_ctx {
   int tune_c, tune_k;
   size_t msm_chunk;  // 0 = MSM_CHUNK; BN256_MSM_CHUNK_LOG2 in the environment overrides (experiments)
   int sort1;         // BN256_SORT1=1 forces the single-pass sort (experiments)
-  int sort2_tiles;   // BN256_SORT2_TILES overrides the tile count of the two-pass sort (experiments)
   int lds_attr2_set;
   int lds_attr_set;
   u32* h_pack;      // pinned
@@ -101,10 +100,7 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   memset(ctx, 0, sizeof *ctx);
   ctx->device = device;
   if (const char* e = getenv("BN256_SORT1")) ctx->sort1 = atoi(e);
-  if (const char* e = getenv("BN256_SORT2_TILES")) {
-    int t = atoi(e);
-    if (t >= 32 && t <= 4096 && t % 32 == 0) ctx->sort2_tiles = t;
-  }
+
   if (const char* e = getenv("BN256_MSM_CHUNK_LOG2")) {
     int lg = atoi(e);
     if (lg >= 10 && lg <= 30) ctx->msm_chunk = (size_t)1 << lg;
@@ -320,23 +316,31 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   const bool use_lds = (size_t)nb * 4 <= 128 * 1024;
   const size_t lds_bytes = (size_t)nb * 4;
   const u32 want_tiles = std::max<u32>(1, 256 / nsets);
-  // two-pass sort (kernels.cuh "two-pass sort"): one set of 2^15 buckets, 256 full tiles, and a
-  // record (window, index, sign, low key bits) that fits 32 bits
+  // two-pass sort (kernels.cuh "two-pass sort"): one set of 2^15 buckets, <= 16 windows, a record
+  // (window, index, sign, low key bits) that fits 32 bits, and groups that average <= 2^15 records
   u32 ibits = 0, wbits = 0;
   while (((size_t)1 << ibits) < nmax) ibits++;
   while ((1u << wbits) < (u32)W) wbits++;
-  const u32 G2 = nb >> SORT2_LB;
-  const u32 tiles2 = ctx->sort2_tiles ? (u32)ctx->sort2_tiles : 256u;  // tiles of pass A
-  const bool two_pass = precomp && nsets == 1 && nb == (1u << 15) && !ctx->sort1 && tiles2 % SORT2_S == 0 &&
-                        wbits + ibits + 1 + SORT2_LB <= 32;
+  const u32 LB2 = entries_max <= (1ull << 24) ? 6u : 5u;
+  const u32 G2 = nb >> LB2;
+  auto tiles2_for = [&](size_t m) -> u32 {
+    u32 t = (u32)((m + SORT2_TILE - 1) / SORT2_TILE);
+    return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
+  };
+  const u32 tiles2_max = tiles2_for(nmax);
+  const bool two_pass = precomp && nsets == 1 && nb == (1u << 15) && !ctx->sort1 && (size_t)W * SORT2_TILE <= 32768 &&
+                        entries_max <= (1ull << 25) && wbits + ibits + 1 + LB2 <= 32;
+  const size_t lds_part0 = (size_t)16 * G2 * 4, lds_part1 = ((size_t)3 * G2 + 32768) * 4;
+  const size_t lds_gsort = ((size_t)17 * (1u << LB2) + SORT2_CAP) * 4;
   if (two_pass) {
-    // records of pass A; also the per-tile histograms of a ragged last pass that falls back
+    // records of pass A; also the per-tile histograms of a short last pass that falls back
     if ((rc = ws_reserve(ctx, WS_RANK, std::max<size_t>(entries_max * 4, (size_t)nsets * want_tiles * nb * 4)))) return rc;
-    if ((rc = ws_reserve(ctx, WS_GBASE, ((size_t)G2 * tiles2 + 1) * 4))) return rc;
+    if ((rc = ws_reserve(ctx, WS_GBASE, ((size_t)G2 * tiles2_max + 1) * 4))) return rc;
     if ((rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nb * SORT2_S + 1) * 4))) return rc;
-    if ((rc = ws_reserve(ctx, WS_SUBSCAN, ((size_t)nb * SORT2_S + 1) * 4))) return rc;
     if (!ctx->lds_attr2_set) {
       HIPCHK(hipFuncSetAttribute((const void*)k_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       ctx->lds_attr2_set = 1;
     }
   }
@@ -363,8 +367,8 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   const size_t Tmax = std::max(threads_for(nmax), threads_for(n - (nchunks - 1) * nmax));
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
-  const size_t ncount = two_pass ? std::max<size_t>(nbt + 1, (size_t)G2 * tiles2 + 1) : nbt + 1;
-  const size_t nscan_max = two_pass ? nblocks((size_t)nb * SORT2_S + 1, SCAN_TILE) : nscan;
+  const size_t ncount = two_pass ? std::max<size_t>(nbt + 1, (size_t)G2 * tiles2_max + 1) : nbt + 1;
+  const size_t nscan_max = two_pass ? std::max<size_t>(nscan, nblocks((size_t)G2 * tiles2_max + 1, SCAN_TILE)) : nscan;
   if ((rc = ws_reserve(ctx, WS_COUNTS, ncount * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BLOCKSUM, (size_t)(nscan_max + 1) * 4))) return rc;
@@ -409,11 +413,6 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
     const bool two = two_pass && n_ch >= ((size_t)1 << 18);
-    if (two) {
-      ntiles = tiles2;
-      tile_len = (u32)((n_ch + ntiles - 1) / ntiles);
-      if ((size_t)tile_len * (ntiles - 1) >= n_ch) return BN256_EINVAL;  // every tile non-empty (n_ch >= 2^18)
-    }
     auto scan = [&](const u32* in, u32* out, size_t m) {
       u32 nblk = nblocks(m, SCAN_TILE);
       hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(SCAN_BLOCK), 0, s, in, out, (u32)m, blocksum);
@@ -424,20 +423,22 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
       u32* ghist = counts;
       u32* gbase = (u32*)ctx->ws[WS_GBASE];
       u32* subhist = (u32*)ctx->ws[WS_SUBHIST];
-      u32* subscan = (u32*)ctx->ws[WS_SUBSCAN];
-      const u32 TS = ntiles / SORT2_S;
-      hipLaunchKernelGGL(k_part<false>, dim3(ntiles), dim3(1024), 16 * G2 * 4, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, tile_len,
-                         (u32)sc_stride, G2, ibits, ghist, (const u32*)nullptr, (u32*)nullptr);
+      const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
+      hipLaunchKernelGGL(k_part<false>, dim3(nt2), dim3(1024), lds_part0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
+                         (u32)sc_stride, G2, LB2, ibits, ghist, (const u32*)nullptr, (u32*)nullptr);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
-      scan(ghist, gbase, (size_t)G2 * ntiles + 1);
+      scan(ghist, gbase, (size_t)G2 * nt2 + 1);
       HIPCHK(hipEventRecord(ctx->ev[2], s));
-      hipLaunchKernelGGL(k_part<true>, dim3(ntiles), dim3(1024), G2 * 4, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, tile_len,
-                         (u32)sc_stride, G2, ibits, (u32*)nullptr, (const u32*)gbase, rank);
-      hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), 0, s, (const u32*)rank, (const u32*)gbase, ntiles, TS,
-                         nb, subhist);
-      scan(subhist, subscan, (size_t)nb * SORT2_S + 1);
+      hipLaunchKernelGGL(k_part<true>, dim3(nt2), dim3(1024), lds_part1, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
+                         (u32)sc_stride, G2, LB2, ibits, (u32*)nullptr, (const u32*)gbase, rank);
+      hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)gbase, nt2, nb,
+                         LB2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval);
+      // groups too large for LDS (skewed scalars): split over SORT2_S workgroups; no-ops otherwise
+      hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), 0, s, (const u32*)rank, (const u32*)gbase, nt2, TS,
+                         LB2, subhist);
+      hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(64), 0, s, (const u32*)gbase, nt2, LB2, subhist, offsets);
       hipLaunchKernelGGL(k_group_place, dim3(G2 * SORT2_S), dim3(256), 0, s, (const u32*)rank, (const u32*)gbase,
-                         (const u32*)subscan, ntiles, TS, nb, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval);
+                         (const u32*)subhist, nt2, TS, LB2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, sval);
     } else {
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,

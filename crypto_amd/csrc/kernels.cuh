@@ -171,32 +171,78 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
 
 // ------------------------------------------------------------------ two-pass sort (fixed-base, c = 16)
 // The single-pass scatter above writes every 4-byte entry to its own place in a 64 MiB array:
-// one 32-byte HBM sector per entry (PMC WRITE_SIZE 526 MB for 67 MB of entries).  With a table
-// (one set of nb = 2^15 buckets) the sort is split so that every store lands in a small number
-// of open lines that the L2 can merge:
-//   pass A  k_part<0/1>      tile of scalars -> G = nb/B groups (high key bits): per-tile group
-//                            counts, scan, then records ((w,i,sign) << LB | low key bits) written
-//                            group-major / tile-major; 512 open lines per tile
-//   pass B  k_group_count    group g, sub-part s (1/S of the tiles): LDS histogram of the B = 64 low
-//           k_group_place    keys -> scan over (bucket, sub-part) -> final positions; 64 open
-//                            lines per workgroup.  Also emits offsets[] for k_accumulate.
-// A group that holds nearly all entries (skewed scalars) is still spread over S workgroups.
-#define SORT2_LB 6u    // log2 buckets per group
-#define SORT2_S 32u    // sub-parts per group
+// one 32-byte HBM sector per entry (PMC WRITE_SIZE 526 MB for 67 MB of entries), and even with
+// perfect merging in L2 one L2 write transaction per entry (~300 G/s: 54 us for 16.7 M entries).
+// With a table (one set of nb = 2^15 buckets) the sort is split in two passes that are both
+// staged through LDS so that every global store is a coalesced run:
+//   pass A  k_part<0>        tile of 2048 scalars -> counts per group (G = nb >> LB groups = high key
+//                            bits); scan over (group, tile)
+//           k_part<1>        same tile: counting sort by group inside LDS (<= 32768 records), then
+//                            each group's run is copied out contiguously.  record =
+//                            ((window, index, sign) << LB) | low key bits
+//   pass B  k_group_sort     one workgroup per group: counting sort of the group's records
+//                            (<= SORT2_CAP, all in LDS) by the low key bits, coalesced copy-out of
+//                            the final entries, and offsets[] for k_accumulate
+//   fallback for a group larger than SORT2_CAP (skewed scalars put nearly every entry into one
+//   group): k_group_count / k_group_subscan / k_group_place split the group over S workgroups with
+//   direct stores; they return at once for ordinary groups.
+#define SORT2_S 32u          // sub-parts per oversized group
+#define SORT2_TILE 2048u     // scalars per tile of pass A
+#define SORT2_CAP 36864u     // records of one group that pass B sorts inside LDS (144 KiB)
 template <bool SCATTER>
-__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 tile_len,
-                                               u32 sc_stride, u32 G, u32 ibits, u32* __restrict__ ghist,
+__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 sc_stride,
+                                               u32 G, u32 LB, u32 ibits, u32* __restrict__ ghist,
                                                const u32* __restrict__ gbase, u32* __restrict__ rec) {
-  extern __shared__ u32 lds[];  // SCATTER: cursor[G]; else per-wave histograms [16][G]
-  const u32 tile = blockIdx.x, ntiles = gridDim.x, wave = threadIdx.x >> 6;
-  if (!SCATTER) {
-    for (u32 j = threadIdx.x; j < 16 * G; j += blockDim.x) lds[j] = 0;
-  } else {
-    for (u32 j = threadIdx.x; j < G; j += blockDim.x) lds[j] = gbase[(size_t)j * ntiles + tile];
+  extern __shared__ u32 lds[];  // count: per-wave histograms [16][G];  scatter: cnt[G], cur[G], dst[G], stage[]
+  const u32 tile = blockIdx.x, ntiles = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const u32 nz = SCATTER ? G : 16 * G;
+  for (u32 j = threadIdx.x; j < nz; j += blockDim.x) lds[j] = 0;
+  __syncthreads();
+  u32* cnt = SCATTER ? lds : lds + wave * G;
+  u32* cur = lds + G;
+  u32* gdst = lds + 2 * G;
+  u32* stage = lds + 3 * G;
+  if (SCATTER)  // this tile's destination of every group, fetched once (strided reads, all in flight together)
+    for (u32 j = threadIdx.x; j < G; j += blockDim.x) gdst[j] = gbase[(size_t)j * ntiles + tile];
+  const u32 lo = tile * SORT2_TILE;
+  const u32 hi = lo >= n ? lo : ((n - lo > SORT2_TILE) ? lo + SORT2_TILE : n);
+  const u32 lmask = (1u << LB) - 1u;
+  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u32 k[8];
+    scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
+    bool neg = scalar_reduce_signed(k);
+    u32 carry = 0;
+    for (u32 w = 0; w < W; w++) {
+      u32 mag, sign;
+      recode_digit(k, neg, w, c, carry, mag, sign);
+      if (mag != 0) atomicAdd(&cnt[(mag - 1) >> LB], 1u);
+    }
   }
   __syncthreads();
-  u32 lo = tile * tile_len;
-  u32 hi = (n - lo > tile_len) ? lo + tile_len : n;
+  if (!SCATTER) {
+    for (u32 j = threadIdx.x; j < G; j += blockDim.x) {
+      u32 t = 0;
+#pragma unroll
+      for (u32 v = 0; v < 16; v++) t += lds[v * G + j];
+      ghist[(size_t)j * ntiles + tile] = t;
+    }
+    if (tile == 0 && threadIdx.x == 0) ghist[(size_t)G * ntiles] = 0;  // sentinel: scan yields the total
+    return;
+  }
+  // exclusive scan of cnt[0..G) (G <= 1024 = blockDim) -> cur; stage[] is the scratch
+  const u32 j = threadIdx.x;
+  u32 own = j < G ? cnt[j] : 0;
+  stage[j] = own;
+  __syncthreads();
+  for (u32 d = 1; d < G; d <<= 1) {
+    u32 t = (j >= d) ? stage[j - d] : 0;
+    __syncthreads();
+    stage[j] += t;
+    __syncthreads();
+  }
+  if (j < G) cur[j] = stage[j] - own;
+  __syncthreads();
+  // second recode: place records by group inside LDS
   for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     u32 k[8];
     scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
@@ -206,35 +252,81 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
       u32 mag, sign;
       recode_digit(k, neg, w, c, carry, mag, sign);
       if (mag == 0) continue;
-      u32 key = mag - 1, grp = key >> SORT2_LB;
-      if (!SCATTER) {
-        atomicAdd(&lds[wave * G + grp], 1u);
-      } else {
-        u32 pos = atomicAdd(&lds[grp], 1u);
-        rec[pos] = (((((w << ibits) | i) << 1) | sign) << SORT2_LB) | (key & ((1u << SORT2_LB) - 1u));
-      }
+      u32 key = mag - 1;
+      u32 pos = atomicAdd(&cur[key >> LB], 1u);
+      stage[pos] = (((((w << ibits) | i) << 1) | sign) << LB) | (key & lmask);
     }
   }
-  if (!SCATTER) {
-    __syncthreads();
-    for (u32 j = threadIdx.x; j < G; j += blockDim.x) {
-      u32 t = 0;
-#pragma unroll
-      for (u32 v = 0; v < 16; v++) t += lds[v * G + j];
-      ghist[(size_t)j * ntiles + tile] = t;
-    }
-    if (tile == 0 && threadIdx.x == 0) ghist[(size_t)G * ntiles] = 0;  // sentinel: scan yields the total
+  __syncthreads();
+  // copy-out: group g's run (cur[g] now points past its end) goes to rec[gbase[g][tile] ...]
+  for (u32 g = wave; g < G; g += 16) {
+    u32 cn = cnt[g], src = cur[g] - cn, dst = gdst[g];
+    for (u32 t = lane; t < cn; t += 64) rec[dst + t] = stage[src + t];
   }
 }
 
-// gbase: exclusive scan of ghist (G*ntiles + 1 entries).  Block (g, s) owns the records of tiles
-// [s*TS, (s+1)*TS) of group g, a contiguous range of rec[].
+// One workgroup per group: the group's records are rec[gbase[g*ntiles] .. gbase[(g+1)*ntiles]).
+__global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec, const u32* __restrict__ gbase, u32 ntiles,
+                                                     u32 nb, u32 LB, u32 ibits, u32 base_off, u32 pt_stride,
+                                                     u32 level_stride, u32* __restrict__ offsets, u32* __restrict__ sval) {
+  extern __shared__ u32 lds[];  // wcnt[16][B], cur[B], stage[m]
+  const u32 B = 1u << LB, g = blockIdx.x, wave = threadIdx.x >> 6;
+  const u32 gs = gbase[(size_t)g * ntiles], ge = gbase[(size_t)(g + 1) * ntiles], m = ge - gs;
+  if (g == gridDim.x - 1 && threadIdx.x == 0) offsets[nb] = ge;
+  if (m > SORT2_CAP) return;  // left to the split kernels below
+  u32* wcnt = lds;
+  u32* cur = lds + 16 * B;
+  u32* stage = cur + B;
+  for (u32 j = threadIdx.x; j < 16 * B; j += blockDim.x) wcnt[j] = 0;
+  __syncthreads();
+  // the thread's records stay in registers for both LDS passes (m <= SORT2_CAP = 36 * 1024)
+  u32 r[SORT2_CAP / 1024];
+#pragma unroll
+  for (u32 it = 0; it < SORT2_CAP / 1024; it++) {
+    u32 e = it * 1024 + threadIdx.x;
+    r[it] = e < m ? rec[gs + e] : 0u;
+  }
+#pragma unroll
+  for (u32 it = 0; it < SORT2_CAP / 1024; it++)
+    if (it * 1024 + threadIdx.x < m) atomicAdd(&wcnt[wave * B + (r[it] & (B - 1))], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {  // one wave: bucket totals and their exclusive scan (B <= 64)
+    u32 b = threadIdx.x, t = 0;
+    if (b < B)
+      for (u32 v = 0; v < 16; v++) t += wcnt[v * B + b];
+    u32 incl = t;
+    for (u32 d = 1; d < 64; d <<= 1) {
+      u32 up = __shfl_up(incl, d, 64);
+      if (b >= d) incl += up;
+    }
+    if (b < B) {
+      cur[b] = incl - t;
+      offsets[g * B + b] = gs + incl - t;
+    }
+  }
+  __syncthreads();
+  const u32 imask = (1u << ibits) - 1u;
+#pragma unroll
+  for (u32 it = 0; it < SORT2_CAP / 1024; it++) {
+    if (it * 1024 + threadIdx.x < m) {
+      u32 pos = atomicAdd(&cur[r[it] & (B - 1)], 1u);
+      u32 v = r[it] >> LB, idx = v >> 1;
+      u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & imask) * pt_stride;
+      stage[pos] = (tidx << 1) | (v & 1u);
+    }
+  }
+  __syncthreads();
+  for (u32 e = threadIdx.x; e < m; e += blockDim.x) sval[gs + e] = stage[e];
+}
+
+// ---- split path for oversized groups.  Block (g, sp) owns the records of tiles [sp*TS, (sp+1)*TS).
 __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ gbase,
-                                                     u32 ntiles, u32 TS, u32 nb, u32* __restrict__ subhist) {
-  __shared__ u32 h[4][1u << SORT2_LB];
-  const u32 B = 1u << SORT2_LB;
+                                                     u32 ntiles, u32 TS, u32 LB, u32* __restrict__ subhist) {
+  __shared__ u32 h[4][64];
+  const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S, wave = threadIdx.x >> 6;
-  h[threadIdx.x >> SORT2_LB][threadIdx.x & (B - 1)] = 0;  // 256 threads == 4 * 64 counters
+  if (gbase[(size_t)(g + 1) * ntiles] - gbase[(size_t)g * ntiles] <= SORT2_CAP) return;
+  h[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
   __syncthreads();
   const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
   for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&h[wave][rec[e] & (B - 1)], 1u);
@@ -243,32 +335,49 @@ __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec
     u32 b = threadIdx.x;
     subhist[((size_t)g * B + b) * SORT2_S + sp] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) subhist[(size_t)nb * SORT2_S] = 0;  // sentinel
 }
-
-// subscan: exclusive scan of subhist (nb*S + 1 entries) = first position of (bucket, sub-part).
-__global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec, const u32* __restrict__ gbase,
-                                                     const u32* __restrict__ subscan, u32 ntiles, u32 TS, u32 nb,
-                                                     u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
-                                                     u32* __restrict__ offsets, u32* __restrict__ sval) {
-  __shared__ u32 cur[1u << SORT2_LB];
-  const u32 B = 1u << SORT2_LB;
-  const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
-  if (threadIdx.x < B) {
-    u32 b = threadIdx.x;
-    u32 p = subscan[((size_t)g * B + b) * SORT2_S + sp];
-    cur[b] = p;
-    if (sp == 0) offsets[g * B + b] = p;
+// exclusive scan, in place, of an oversized group's B*S counters (bucket-major), offset by the group start
+__global__ void __launch_bounds__(64) k_group_subscan(const u32* __restrict__ gbase, u32 ntiles, u32 LB,
+                                                      u32* __restrict__ subhist, u32* __restrict__ offsets) {
+  const u32 B = 1u << LB, g = blockIdx.x, b = threadIdx.x;
+  const u32 gs = gbase[(size_t)g * ntiles];
+  if (gbase[(size_t)(g + 1) * ntiles] - gs <= SORT2_CAP) return;
+  u32* row = subhist + ((size_t)g * B + b) * SORT2_S;  // lane b owns bucket b's S counters
+  u32 t = 0;
+  if (b < B)
+    for (u32 v = 0; v < SORT2_S; v++) t += row[v];
+  u32 incl = t;
+  for (u32 d = 1; d < 64; d <<= 1) {
+    u32 up = __shfl_up(incl, d, 64);
+    if (b >= d) incl += up;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nb] = subscan[(size_t)nb * SORT2_S];
+  if (b < B) {
+    u32 run = gs + incl - t;
+    offsets[g * B + b] = run;
+    for (u32 v = 0; v < SORT2_S; v++) {
+      u32 cnt = row[v];
+      row[v] = run;
+      run += cnt;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec, const u32* __restrict__ gbase,
+                                                     const u32* __restrict__ subscan, u32 ntiles, u32 TS, u32 LB,
+                                                     u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
+                                                     u32* __restrict__ sval) {
+  __shared__ u32 cur[64];
+  const u32 B = 1u << LB;
+  const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
+  if (gbase[(size_t)(g + 1) * ntiles] - gbase[(size_t)g * ntiles] <= SORT2_CAP) return;
+  if (threadIdx.x < B) cur[threadIdx.x] = subscan[((size_t)g * B + threadIdx.x) * SORT2_S + sp];
   __syncthreads();
   const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
+  const u32 imask = (1u << ibits) - 1u;
   for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) {
     u32 r = rec[e];
     u32 pos = atomicAdd(&cur[r & (B - 1)], 1u);
-    u32 v = r >> SORT2_LB;
-    u32 idx = v >> 1;
-    u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & ((1u << ibits) - 1u)) * pt_stride;
+    u32 v = r >> LB, idx = v >> 1;
+    u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & imask) * pt_stride;
     sval[pos] = (tidx << 1) | (v & 1u);
   }
 }
