@@ -581,12 +581,16 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
     if (role == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
     return;
   }
+  // the chain of additions is latency-bound: the next partial is fetched while the current one is added
+  xyzz p;
   xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
+  xyzz_load(p, &partials[2 * (size_t)(t0 + 1)]);
   for (u32 t = t0 + 1; t <= t1; t++) {
-    xyzz p, r;
-    xyzz_load(p, &partials[2 * (size_t)t]);
+    xyzz pn, r;
+    if (t < t1) xyzz_load(pn, &partials[2 * (size_t)(t + 1)]);
     xyzz_add_quad(r, acc, p, role);
     acc = r;
+    p = pn;
   }
   if (role == 0) xyzz_store(&buckets[b], acc);
 }
