@@ -23,7 +23,7 @@ for d in dirs:
                 per_dispatch[key] += float(row["Counter_Value"])
                 names[row["Dispatch_Id"]] = row["Kernel_Name"]
             for (disp, ctr), val in per_dispatch.items():
-                k = re.sub(r"\(.*", "", names[disp])
+                k = re.sub(r"^void ", "", re.sub(r"\(.*", "", names[disp]))
                 acc[k][ctr].append(val)
 res = {}
 for k, ctrs in sorted(acc.items()):
