@@ -328,9 +328,9 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
   };
   const u32 tiles2_max = tiles2_for(nmax);
-  const bool two_pass = precomp && nsets == 1 && nb == (1u << 15) && !ctx->sort1 && (size_t)W * SORT2_TILE <= 32768 &&
+  const bool two_pass = precomp && nsets == 1 && nb == (1u << 15) && !ctx->sort1 && W <= 16 &&
                         entries_max <= (1ull << 25) && wbits + ibits + 1 + LB2 <= 32;
-  const size_t lds_part0 = (size_t)16 * G2 * 4, lds_part1 = ((size_t)3 * G2 + 32768) * 4;
+  const size_t lds_part0 = (size_t)16 * G2 * 4, lds_part1 = ((size_t)3 * G2 + (size_t)W * SORT2_TILE) * 4;
   const size_t lds_gsort = ((size_t)17 * (1u << LB2) + SORT2_CAP) * 4;
   if (two_pass) {
     // records of pass A; also the per-tile histograms of a short last pass that falls back
