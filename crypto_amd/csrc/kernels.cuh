@@ -1,6 +1,7 @@
 // HIP kernels of the BN256 G1 MSM engine (gfx950).  Pipeline of one MSM
 // (vectorPointScalarMul, go/bp/util.go:165-175, go/bppp/util.go:178-196):
 //
+//   k_part<0/1>, k_group_sort   two-pass LDS-staged bucket sort (fixed-base, >= 2^18 points); otherwise:
 //   k_tile_sort<0>    signed c-bit digits of every scalar, per-tile LDS bucket histograms
 //   k_tile_scan       per-bucket prefix over tiles;  k_scan1/2/3: bucket totals -> bucket offsets
 //   k_tile_sort<1>    LDS cursors, scatter of (base index|sign) into bucket order (counting sort)
