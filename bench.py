@@ -39,7 +39,7 @@ def cpu_baseline(sample_terms: int):
     t0 = time.perf_counter()
     out = orc.msm(bases, scalars, mt=False)
     dt = time.perf_counter() - t0
-    return sample_terms / dt, out
+    return sample_terms / dt, out, orc
 
 
 def main():
@@ -160,9 +160,13 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            v, _ = cpu_baseline(args.cpu_sample)
+            v, _, orc = cpu_baseline(args.cpu_sample)
+            # the oracle as checker: exact answer of the whole timed workload from its closed form
+            # (bases are k_i*G0 with known k_i), bit-for-bit against the device result
+            exact = orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, n)
             line["cpu_baseline"] = {
                 "value": v, "unit": "points/s", "cores": 1, "kind": "port",
+                "device_result_matches_oracle_closed_form": bool(exact == result),
                 "sample": f"first {args.cpu_sample} terms of the same seeded workload, reference algorithm "
                           f"(per-term double-and-add + add, go/bp/util.go:165-175) restated in C, 1 thread",
             }

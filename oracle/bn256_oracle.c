@@ -282,6 +282,50 @@ void orc_synth_bases(uint8_t *out_xy, uint64_t seed, size_t first, size_t n) {
     }
 }
 
+/* Closed form of the synthetic MSM: bases are k_i*G0 with known k_i, so
+ * sum_i s_i * (k_i*G0) = (sum_i s_i*k_i mod n) * G0.  Gives the exact answer at sizes (2^20, 2^24)
+ * where the per-term reference loop is infeasible; used only by the tests. */
+#define NQ0 0x056417b72d284e5fULL                /* -n^-1 mod 2^64 */
+static const uint64_t NR2_[4] = {0xb5f030132affbc35ULL, 0x85a1f7da0792e95dULL,
+                                 0x26841e5fa6ee4895ULL, 0x3d8f6c73765aefd5ULL};   /* 2^512 mod n */
+static void fr_mont(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {   /* a*b/2^256 mod n */
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < 4; j++) {
+            u128 cur = (u128)a[j] * b[i] + t[j] + c;
+            t[j] = (uint64_t)cur; c = (uint64_t)(cur >> 64);
+        }
+        u128 cur = (u128)t[4] + c;
+        t[4] = (uint64_t)cur; t[5] = (uint64_t)(cur >> 64);
+        uint64_t m = t[0] * NQ0;
+        cur = (u128)m * N_.l[0] + t[0];
+        c = (uint64_t)(cur >> 64);
+        for (int j = 1; j < 4; j++) {
+            cur = (u128)m * N_.l[j] + t[j] + c;
+            t[j - 1] = (uint64_t)cur; c = (uint64_t)(cur >> 64);
+        }
+        cur = (u128)t[4] + c;
+        t[3] = (uint64_t)cur;
+        t[4] = t[5] + (uint64_t)(cur >> 64);
+    }
+    if (t[4] || geq(t, N_.l)) sub4(r, t, N_.l); else memcpy(r, t, 32);
+}
+/* out_be = sum_{i<n} synth_scalar(seed_s, first+i) * synth_base_scalar(seed_b, first+i) mod n */
+void orc_synth_dot(uint8_t out_be[32], uint64_t seed_b, uint64_t seed_s, size_t first, size_t n) {
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        uint64_t k[4], s[4], kr[4], pr[4];
+        synth_scalar_le(k, seed_b, first + i);
+        if ((k[0] | k[1] | k[2] | k[3]) == 0) k[0] = 1;
+        synth_scalar_le(s, seed_s, first + i);
+        fr_mont(kr, k, NR2_);                    /* k * 2^256 */
+        fr_mont(pr, kr, s);                      /* k * s */
+        if (add4(acc, acc, pr) || geq(acc, N_.l)) sub4(acc, acc, N_.l);
+    }
+    le_to_be32(out_be, acc);
+}
+
 /* Keccak-256, legacy 0x01 padding (iden3 keccak256.Hash, go/bp/util.go:232). */
 static const uint64_t KRC[24] = {
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,

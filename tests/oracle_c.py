@@ -28,6 +28,8 @@ class OracleC:
         L.orc_synth_bases.restype = None
         L.orc_synth_bases_mt.argtypes = [cp, C.c_uint64, sz, sz]
         L.orc_synth_bases_mt.restype = None
+        L.orc_synth_dot.argtypes = [cp, C.c_uint64, C.c_uint64, sz, sz]
+        L.orc_synth_dot.restype = None
         L.orc_keccak256.argtypes = [cp, cp, sz]
         L.orc_keccak256.restype = None
 
@@ -40,6 +42,22 @@ class OracleC:
         buf = C.create_string_buffer(32 * max(n, 1))
         self.L.orc_synth_scalars(buf, seed, first, n)
         return buf.raw[:32 * n]
+
+    def synth_dot(self, seed_b, seed_s, n, first=0) -> int:
+        """sum_i synth_scalar(seed_s, i) * synth_base_scalar(seed_b, i) mod n over [first, first + n)."""
+        out = C.create_string_buffer(32)
+        self.L.orc_synth_dot(out, seed_b, seed_s, first, n)
+        return int.from_bytes(out.raw, "big")
+
+    def synth_msm_closed_form(self, seed_b, seed_s, n, first=0) -> bytes:
+        """The synthetic MSM's exact answer without the per-term loop: the bases are k_i*G0 with
+        known k_i, so the sum is (sum_i s_i*k_i mod n)*G0.  Feasible at 2^24 terms."""
+        g0 = (1).to_bytes(32, "big") + (0x8fb501e34aa387f9aa6fecb86184dc21ee5b88d120b5b59e185cac6c5e089667 - 2).to_bytes(32, "big")
+        out = C.create_string_buffer(64)
+        rc = self.L.orc_g1_scalar_mult(out, g0, self.synth_dot(seed_b, seed_s, n, first).to_bytes(32, "big"))
+        if rc:
+            raise ValueError(f"oracle rc {rc}")
+        return out.raw
 
     def msm(self, bases: bytes, scalars: bytes, mt: bool = False) -> bytes:
         """vectorPointScalarMul (go/bp/util.go:165-175) on marshalled inputs."""

@@ -319,3 +319,22 @@ def test_two_pass_sort_matches_single_pass(monkeypatch):
     finally:
         e1.close()
         e2.close()
+
+
+@pytest.mark.parametrize("log2n,flags", [(20, 1), (20, 0), (22, 1), (24, 1)])
+def test_full_size_exact_answer(eng, orc, log2n, flags):
+    """BASELINE.json sizes (2^20, 2^24 points): the device result against the closed form of the
+    synthetic workload, (sum_i s_i k_i mod n) * G0 -- an exact, bit-for-bit check at sizes where
+    the reference's per-term loop would take hours on the CPU."""
+    n = 1 << log2n
+    bases = eng.random_bases(0x5EED0001, n, flags=flags)
+    v = eng.fr_random(0x5EED0002, n)
+    try:
+        got = eng.msm_fr(bases, 0, 1, n, v)
+        assert got == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, n)
+        # a sub-range that starts and ends inside passes / tiles
+        off, m = 12345, n - 54321
+        assert eng.msm_fr(bases, off, 1, m, v, off, 1) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, m, first=off)
+    finally:
+        bases.free()
+        v.free()

@@ -166,3 +166,16 @@ def test_inner_product_argument_walkthrough_inputs():
         ref.vector_mul(a[:2], b)
     assert ref.inner_arg_verify(ref.InnerArgumentPublic(3, pub.G[:3], pub.H[:3], pub.U), Pm, L, R, fa, fb) \
         == "invalid n: should be 2^x"
+
+
+def test_synthetic_closed_form_matches_the_term_loop(orc):
+    """orc.synth_msm_closed_form (used by the full-size GPU tests) against the reference loop and
+    against the Python restatement's definition of the synthetic workload."""
+    import bn256_ref as ref
+    sb, ss, n = 0x5EED0001, 0x5EED0002, 300
+    want = sum(ref.synth_scalar(ss, i) * ref.synth_base_scalar(sb, i) for i in range(n)) % ref.N
+    assert orc.synth_dot(sb, ss, n) == want
+    assert orc.synth_dot(sb, ss, 100, first=200) == sum(
+        ref.synth_scalar(ss, i) * ref.synth_base_scalar(sb, i) for i in range(200, 300)) % ref.N
+    assert orc.synth_msm_closed_form(sb, ss, n) == orc.msm(orc.synth_bases(sb, n), orc.synth_scalars(ss, n))
+    assert orc.synth_msm_closed_form(sb, ss, n) == ref.marshal(ref.base_mul(want))
