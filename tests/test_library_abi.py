@@ -38,6 +38,18 @@ def test_strerror_and_null_arguments():
     lib.bn256_ctx_destroy(None)
     lib.bn256_bases_free(None, None)
     assert lib.bn256_bases_len(None) == 0
+    # Fr vectors / batched commitments: argument checks come before any HIP call
+    h = C.c_void_p()
+    assert lib.bn256_fr_upload(None, None, 0, C.byref(h)) == -1
+    assert lib.bn256_fr_random(None, 1, 0, 4, C.byref(h)) == -1
+    assert lib.bn256_fr_len(None) == 0 and not lib.bn256_fr_device_ptr(None)
+    lib.bn256_fr_free(None, None)
+    o32 = C.create_string_buffer(32)
+    assert lib.bn256_fr_dot(None, None, 0, 1, 0, None, 0, 1, 0, None, o32) == -1
+    assert lib.bn256_fr_fold(None, None, 0, 0, None, 0, 0, 1, o32, o32, C.byref(h)) == -1
+    assert lib.bn256_msm_fr(None, None, 0, 1, 0, None, 0, 1, out) == -1
+    assert lib.bn256_msm_fr_multi(None, 0, None, None, None, None, None, None, None, None, out) == -1
+    assert lib.bn256_com_batch(None, out, out, None, None, 0, C.byref(h)) == -1
 
 
 def test_host_g1_sum_matches_oracle():
