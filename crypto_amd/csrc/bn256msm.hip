@@ -316,31 +316,35 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   const bool use_lds = (size_t)nb * 4 <= 128 * 1024;
   const size_t lds_bytes = (size_t)nb * 4;
   const u32 want_tiles = std::max<u32>(1, 256 / nsets);
-  // two-pass sort (kernels.cuh "two-pass sort"): one set of 2^15 buckets, <= 16 windows, a record
-  // (window, index, sign, low key bits) that fits 32 bits, and groups that average <= 2^15 records
+  // two-pass sort (kernels.cuh "two-pass sort"): 2^15 buckets per set, <= 16 windows, <= 1024 groups
+  // that average <= 2^15 records, and a record that fits 32 bits: (window, index, sign, low key
+  // bits) with a table; (index, sign, low key bits) without (the group implies the window)
   u32 ibits = 0, wbits = 0;
   while (((size_t)1 << ibits) < nmax) ibits++;
   while ((1u << wbits) < (u32)W) wbits++;
-  const u32 LB2 = entries_max <= (1ull << 24) ? 6u : 5u;
-  const u32 G2 = nb >> LB2;
+  const u32 LB2 = precomp ? (entries_max <= (1ull << 24) ? 6u : 5u) : 9u;  // log2 keys per group
+  const u32 NH2 = LB2 <= 6 ? 16u : 4u;                                      // histogram copies in pass B
+  const u32 G2 = (u32)(nbt >> LB2);
+  const u32 key_stride = precomp ? 0u : nb;
   auto tiles2_for = [&](size_t m) -> u32 {
     u32 t = (u32)((m + SORT2_TILE - 1) / SORT2_TILE);
     return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
   };
   const u32 tiles2_max = tiles2_for(nmax);
-  const bool two_pass = precomp && nsets == 1 && nb == (1u << 15) && !ctx->sort1 && W <= 16 &&
-                        entries_max <= (1ull << 25) && wbits + ibits + 1 + LB2 <= 32;
+  const bool two_pass = nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 &&
+                        entries_max <= (unsigned long long)G2 * 32768 &&
+                        (precomp ? wbits + ibits + 1 + LB2 <= 32 : ibits + 1 + LB2 <= 32);
   const size_t lds_part0 = (size_t)16 * G2 * 4, lds_part1 = ((size_t)3 * G2 + (size_t)W * SORT2_TILE) * 4;
-  const size_t lds_gsort = ((size_t)17 * (1u << LB2) + SORT2_CAP) * 4;
+  const size_t lds_gsort = ((size_t)(NH2 + 2) * (1u << LB2) + SORT2_CAP) * 4;
   if (two_pass) {
     // records of pass A; also the per-tile histograms of a short last pass that falls back
     if ((rc = ws_reserve(ctx, WS_RANK, std::max<size_t>(entries_max * 4, (size_t)nsets * want_tiles * nb * 4)))) return rc;
     if ((rc = ws_reserve(ctx, WS_GBASE, ((size_t)G2 * tiles2_max + 1) * 4))) return rc;
-    if ((rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nb * SORT2_S + 1) * 4))) return rc;
+    if ((rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nbt * SORT2_S + 1) * 4))) return rc;
     if (!ctx->lds_attr2_set) {
       HIPCHK(hipFuncSetAttribute((const void*)k_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)k_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       ctx->lds_attr2_set = 1;
     }
   }
@@ -412,7 +416,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
-    const bool two = two_pass && n_ch >= ((size_t)1 << 18);
+    const bool two = two_pass && n_ch >= ((size_t)1 << (precomp ? 18 : 19));  // below: fixed costs of the 2^9..2^10 groups dominate
     auto scan = [&](const u32* in, u32* out, size_t m) {
       u32 nblk = nblocks(m, SCAN_TILE);
       hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(SCAN_BLOCK), 0, s, in, out, (u32)m, blocksum);
@@ -425,19 +429,20 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
       u32* subhist = (u32*)ctx->ws[WS_SUBHIST];
       const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
       hipLaunchKernelGGL(k_part<false>, dim3(nt2), dim3(1024), lds_part0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
-                         (u32)sc_stride, G2, LB2, ibits, ghist, (const u32*)nullptr, (u32*)nullptr);
+                         (u32)sc_stride, G2, LB2, ibits, key_stride, ghist, (const u32*)nullptr, (u32*)nullptr);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
       scan(ghist, gbase, (size_t)G2 * nt2 + 1);
       HIPCHK(hipEventRecord(ctx->ev[2], s));
       hipLaunchKernelGGL(k_part<true>, dim3(nt2), dim3(1024), lds_part1, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
-                         (u32)sc_stride, G2, LB2, ibits, (u32*)nullptr, (const u32*)gbase, rank);
-      hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)gbase, nt2, nb,
-                         LB2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval);
+                         (u32)sc_stride, G2, LB2, ibits, key_stride, (u32*)nullptr, (const u32*)gbase, rank);
+      hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)gbase, nt2,
+                         (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval);
       // groups too large for LDS (skewed scalars): split over SORT2_S workgroups; no-ops otherwise
-      hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), 0, s, (const u32*)rank, (const u32*)gbase, nt2, TS,
-                         LB2, subhist);
-      hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(64), 0, s, (const u32*)gbase, nt2, LB2, subhist, offsets);
-      hipLaunchKernelGGL(k_group_place, dim3(G2 * SORT2_S), dim3(256), 0, s, (const u32*)rank, (const u32*)gbase,
+      hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), (size_t)4 * (1u << LB2) * 4, s, (const u32*)rank,
+                         (const u32*)gbase, nt2, TS, LB2, subhist);
+      hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(1024), 0, s, (const u32*)gbase, nt2, LB2, subhist, offsets);
+      hipLaunchKernelGGL(k_group_place, dim3(G2 * SORT2_S), dim3(256), (size_t)(1u << LB2) * 4, s, (const u32*)rank,
+                         (const u32*)gbase,
                          (const u32*)subhist, nt2, TS, LB2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, sval);
     } else {
     if (use_lds) {

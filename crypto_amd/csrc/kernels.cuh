@@ -192,8 +192,10 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
 #define SORT2_CAP 36864u     // records of one group that pass B sorts inside LDS (144 KiB)
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 sc_stride,
-                                               u32 G, u32 LB, u32 ibits, u32* __restrict__ ghist,
+                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32* __restrict__ ghist,
                                                const u32* __restrict__ gbase, u32* __restrict__ rec) {
+  // key = w * key_stride + |digit| - 1: key_stride = 0 with a table (one bucket set, the window is
+  // kept in the record), nb without (one bucket set per window, the window is implied by the group)
   extern __shared__ u32 lds[];  // count: per-wave histograms [16][G];  scatter: cnt[G], cur[G], dst[G], stage[]
   const u32 tile = blockIdx.x, ntiles = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u32 nz = SCATTER ? G : 16 * G;
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
     for (u32 w = 0; w < W; w++) {
       u32 mag, sign;
       recode_digit(k, neg, w, c, carry, mag, sign);
-      if (mag != 0) atomicAdd(&cnt[(mag - 1) >> LB], 1u);
+      if (mag != 0) atomicAdd(&cnt[(w * key_stride + mag - 1) >> LB], 1u);
     }
   }
   __syncthreads();
@@ -253,9 +255,10 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
       u32 mag, sign;
       recode_digit(k, neg, w, c, carry, mag, sign);
       if (mag == 0) continue;
-      u32 key = mag - 1;
+      u32 key = w * key_stride + mag - 1;
       u32 pos = atomicAdd(&cur[key >> LB], 1u);
-      stage[pos] = (((((w << ibits) | i) << 1) | sign) << LB) | (key & lmask);
+      u32 wfield = key_stride ? 0u : (w << ibits);
+      stage[pos] = ((((wfield | i) << 1) | sign) << LB) | (key & lmask);
     }
   }
   __syncthreads();
@@ -266,19 +269,36 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
   }
 }
 
+// Exclusive scan of v over the first B (<= blockDim = 1024) threads through LDS scratch tmp[B..];
+// every thread of the block must call it.
+__device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32 B, u32* tmp) {
+  const u32 j = threadIdx.x;
+  if (j < B) tmp[j] = v;
+  __syncthreads();
+  for (u32 d = 1; d < B; d <<= 1) {
+    u32 t = (j < B && j >= d) ? tmp[j - d] : 0;
+    __syncthreads();
+    if (j < B) tmp[j] += t;
+    __syncthreads();
+  }
+  return j < B ? tmp[j] - v : 0;
+}
+
 // One workgroup per group: the group's records are rec[gbase[g*ntiles] .. gbase[(g+1)*ntiles]).
+// B = 2^LB keys per group (<= 512); NH histogram copies spread the LDS atomics.
 __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec, const u32* __restrict__ gbase, u32 ntiles,
-                                                     u32 nb, u32 LB, u32 ibits, u32 base_off, u32 pt_stride,
+                                                     u32 nbt, u32 LB, u32 NH, u32 ibits, u32 base_off, u32 pt_stride,
                                                      u32 level_stride, u32* __restrict__ offsets, u32* __restrict__ sval) {
-  extern __shared__ u32 lds[];  // wcnt[16][B], cur[B], stage[m]
+  extern __shared__ u32 lds[];  // wcnt[NH][B], cur[B], tmp[B], stage[m]
   const u32 B = 1u << LB, g = blockIdx.x, wave = threadIdx.x >> 6;
   const u32 gs = gbase[(size_t)g * ntiles], ge = gbase[(size_t)(g + 1) * ntiles], m = ge - gs;
-  if (g == gridDim.x - 1 && threadIdx.x == 0) offsets[nb] = ge;
+  if (g == gridDim.x - 1 && threadIdx.x == 0) offsets[nbt] = ge;
   if (m > SORT2_CAP) return;  // left to the split kernels below
   u32* wcnt = lds;
-  u32* cur = lds + 16 * B;
-  u32* stage = cur + B;
-  for (u32 j = threadIdx.x; j < 16 * B; j += blockDim.x) wcnt[j] = 0;
+  u32* cur = lds + NH * B;
+  u32* tmp = cur + B;
+  u32* stage = tmp + B;
+  for (u32 j = threadIdx.x; j < NH * B; j += blockDim.x) wcnt[j] = 0;
   __syncthreads();
   // the thread's records stay in registers for both LDS passes (m <= SORT2_CAP = 36 * 1024)
   u32 r[SORT2_CAP / 1024];
@@ -287,23 +307,18 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
     u32 e = it * 1024 + threadIdx.x;
     r[it] = e < m ? rec[gs + e] : 0u;
   }
+  const u32 hrow = (wave & (NH - 1)) * B;
 #pragma unroll
   for (u32 it = 0; it < SORT2_CAP / 1024; it++)
-    if (it * 1024 + threadIdx.x < m) atomicAdd(&wcnt[wave * B + (r[it] & (B - 1))], 1u);
+    if (it * 1024 + threadIdx.x < m) atomicAdd(&wcnt[hrow + (r[it] & (B - 1))], 1u);
   __syncthreads();
-  if (threadIdx.x < 64) {  // one wave: bucket totals and their exclusive scan (B <= 64)
-    u32 b = threadIdx.x, t = 0;
-    if (b < B)
-      for (u32 v = 0; v < 16; v++) t += wcnt[v * B + b];
-    u32 incl = t;
-    for (u32 d = 1; d < 64; d <<= 1) {
-      u32 up = __shfl_up(incl, d, 64);
-      if (b >= d) incl += up;
-    }
-    if (b < B) {
-      cur[b] = incl - t;
-      offsets[g * B + b] = gs + incl - t;
-    }
+  u32 t = 0;
+  if (threadIdx.x < B)
+    for (u32 v = 0; v < NH; v++) t += wcnt[v * B + threadIdx.x];
+  u32 excl = block_exclusive_scan(t, B, tmp);
+  if (threadIdx.x < B) {
+    cur[threadIdx.x] = excl;
+    offsets[g * B + threadIdx.x] = gs + excl;
   }
   __syncthreads();
   const u32 imask = (1u << ibits) - 1u;
@@ -323,37 +338,33 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
 // ---- split path for oversized groups.  Block (g, sp) owns the records of tiles [sp*TS, (sp+1)*TS).
 __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ gbase,
                                                      u32 ntiles, u32 TS, u32 LB, u32* __restrict__ subhist) {
-  __shared__ u32 h[4][64];
+  extern __shared__ u32 lds[];  // h[4][B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S, wave = threadIdx.x >> 6;
   if (gbase[(size_t)(g + 1) * ntiles] - gbase[(size_t)g * ntiles] <= SORT2_CAP) return;
-  h[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
+  for (u32 j = threadIdx.x; j < 4 * B; j += blockDim.x) lds[j] = 0;
   __syncthreads();
   const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
-  for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&h[wave][rec[e] & (B - 1)], 1u);
+  for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&lds[wave * B + (rec[e] & (B - 1))], 1u);
   __syncthreads();
-  if (threadIdx.x < B) {
-    u32 b = threadIdx.x;
-    subhist[((size_t)g * B + b) * SORT2_S + sp] = h[0][b] + h[1][b] + h[2][b] + h[3][b];
-  }
+  for (u32 b = threadIdx.x; b < B; b += blockDim.x)
+    subhist[((size_t)g * B + b) * SORT2_S + sp] = lds[b] + lds[B + b] + lds[2 * B + b] + lds[3 * B + b];
 }
-// exclusive scan, in place, of an oversized group's B*S counters (bucket-major), offset by the group start
-__global__ void __launch_bounds__(64) k_group_subscan(const u32* __restrict__ gbase, u32 ntiles, u32 LB,
-                                                      u32* __restrict__ subhist, u32* __restrict__ offsets) {
+// exclusive scan, in place, of an oversized group's B*S counters (bucket-major), offset by the group
+// start; one block of 1024 threads per group, thread b owns bucket b's S counters
+__global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ gbase, u32 ntiles, u32 LB,
+                                                        u32* __restrict__ subhist, u32* __restrict__ offsets) {
+  __shared__ u32 tmp[1024];
   const u32 B = 1u << LB, g = blockIdx.x, b = threadIdx.x;
   const u32 gs = gbase[(size_t)g * ntiles];
   if (gbase[(size_t)(g + 1) * ntiles] - gs <= SORT2_CAP) return;
-  u32* row = subhist + ((size_t)g * B + b) * SORT2_S;  // lane b owns bucket b's S counters
+  u32* row = subhist + ((size_t)g * B + b) * SORT2_S;
   u32 t = 0;
   if (b < B)
     for (u32 v = 0; v < SORT2_S; v++) t += row[v];
-  u32 incl = t;
-  for (u32 d = 1; d < 64; d <<= 1) {
-    u32 up = __shfl_up(incl, d, 64);
-    if (b >= d) incl += up;
-  }
+  u32 excl = block_exclusive_scan(t, B, tmp);
   if (b < B) {
-    u32 run = gs + incl - t;
+    u32 run = gs + excl;
     offsets[g * B + b] = run;
     for (u32 v = 0; v < SORT2_S; v++) {
       u32 cnt = row[v];
@@ -366,11 +377,11 @@ __global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec
                                                      const u32* __restrict__ subscan, u32 ntiles, u32 TS, u32 LB,
                                                      u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
                                                      u32* __restrict__ sval) {
-  __shared__ u32 cur[64];
+  extern __shared__ u32 cur[];  // [B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
   if (gbase[(size_t)(g + 1) * ntiles] - gbase[(size_t)g * ntiles] <= SORT2_CAP) return;
-  if (threadIdx.x < B) cur[threadIdx.x] = subscan[((size_t)g * B + threadIdx.x) * SORT2_S + sp];
+  for (u32 b = threadIdx.x; b < B; b += blockDim.x) cur[b] = subscan[((size_t)g * B + b) * SORT2_S + sp];
   __syncthreads();
   const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
   const u32 imask = (1u << ibits) - 1u;
