@@ -34,7 +34,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_GBASE, WS_SUBHIST, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -51,6 +51,7 @@ struct bn256_ctx {
   u32* h_pack;      // pinned
   size_t h_pack_cap;
   u32* d_err;
+  u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy)
   u32* h_err;       // pinned
 };
 
@@ -108,6 +109,7 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc(&ctx->d_err, 256));
+  HIPCHK(hipMalloc(&ctx->d_heavy, (2 + HEAVY_SLOTS) * sizeof(u32)));
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
@@ -124,6 +126,7 @@ extern "C" void bn256_ctx_destroy(bn256_ctx* ctx) {
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->d_err) (void)hipFree(ctx->d_err);
+  if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -371,6 +374,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   const size_t Tmax = std::max(threads_for(nmax), threads_for(n - (nchunks - 1) * nmax));
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
+  if ((rc = ws_reserve(ctx, WS_HEAVYTMP, (size_t)HEAVY_SLOTS * HEAVY_PARTS * sizeof(xyzz_mem)))) return rc;
   const size_t ncount = two_pass ? std::max<size_t>(nbt + 1, (size_t)G2 * tiles2_max + 1) : nbt + 1;
   const size_t nscan_max = two_pass ? std::max<size_t>(nscan, nblocks((size_t)G2 * tiles2_max + 1, SCAN_TILE)) : nscan;
   if ((rc = ws_reserve(ctx, WS_COUNTS, ncount * 4))) return rc;
@@ -392,7 +396,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   xyzz_mem* sum_buckets = nchunks > 1 ? (xyzz_mem*)ctx->ws[WS_BUCKETS2] : buckets;
   xyzz_mem* partials = (xyzz_mem*)ctx->ws[WS_PARTIALS];
   u32* d_pack = (u32*)ctx->ws[WS_PACK];
-  u32* heavy_count = ctx->d_err + 16;
+  u32* heavy_count = ctx->d_heavy;
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
 
@@ -413,7 +417,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     }
 
     HIPCHK(hipEventRecord(ctx->ev[0], s));
-    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, s));
+    HIPCHK(hipMemsetAsync(heavy_count, 0, (2 + HEAVY_SLOTS) * sizeof(u32), s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
     const bool two = two_pass && n_ch >= ((size_t)1 << (precomp ? 18 : 19));  // below: fixed costs of the 2^9..2^10 groups dominate
@@ -478,7 +482,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
                        (const xyzz_mem*)partials, heavy_count, heavy_list);
     hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
-                       (const u32*)heavy_count, (const u32*)heavy_list);
+                       heavy_count, (const u32*)heavy_list, (xyzz_mem*)ctx->ws[WS_HEAVYTMP]);
     if (nchunks > 1) {
       if (ch == 0)
         HIPCHK(hipMemcpyAsync(sum_buckets, buckets, nbt * sizeof(xyzz_mem), hipMemcpyDeviceToDevice, s));

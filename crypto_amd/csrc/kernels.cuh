@@ -572,6 +572,9 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
 // FIX_CAP partials (heavy buckets: skewed scalar distributions such as the Bulletproofs
 // 0/1 bit vectors, go/bp/main.go:84-85, or a narrow top window) are queued for k_heavy.
 #define FIX_CAP 32
+#define HEAVY_SPLIT_MIN 4096u  // partials above which one bucket is reduced by HEAVY_PARTS workgroups
+#define HEAVY_PARTS 64u
+#define HEAVY_SLOTS 1024u      // such buckets per pass (2T / 4096 <= 256 at the default chunk length)
 __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offsets, u32 nbt, u32 K,
                                                    xyzz_mem* __restrict__ buckets,
                                                    const xyzz_mem* __restrict__ partials,
@@ -590,7 +593,16 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
   u32 t0 = lo / K, t1 = (hi - 1) / K;
   if (t0 == t1) return;
   if (t1 - t0 + 1 > FIX_CAP) {
-    if (role == 0) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+    if (role == 0) {
+      // heavy_count[0]: queue length; heavy_count[1]: buckets so heavy that k_heavy splits them
+      // over HEAVY_PARTS workgroups (bit 31 of the queue entry, slot in bits 20..30)
+      u32 ent = b;
+      if (t1 - t0 + 1 > HEAVY_SPLIT_MIN && b < (1u << 20)) {
+        u32 slot = atomicAdd(heavy_count + 1, 1u);
+        if (slot < HEAVY_SLOTS) ent = b | 0x80000000u | (slot << 20);
+      }
+      heavy_list[atomicAdd(heavy_count, 1u)] = ent;
+    }
     return;
   }
   // the chain of additions is latency-bound: the next partial is fetched while the current one is added
@@ -607,40 +619,73 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
   if (role == 0) xyzz_store(&buckets[b], acc);
 }
 
-// One workgroup per heavy bucket: the threads split the partials (strided), then a
-// log-depth tree through LDS.
-__global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, u32 K, xyzz_mem* __restrict__ buckets,
-                                               const xyzz_mem* __restrict__ partials,
-                                               const u32* __restrict__ heavy_count,
-                                               const u32* __restrict__ heavy_list) {
-  __shared__ xyzz_mem sh[256];
-  const u32 nheavy = *heavy_count;
-  for (u32 j = blockIdx.x; j < nheavy; j += gridDim.x) {
-    u32 b = heavy_list[j];
-    u32 t0 = offsets[b] / K, t1 = (offsets[b + 1] - 1) / K;
-    u32 np = t1 - t0 + 1;
-    xyzz acc;
-    xyzz_set_inf(acc);
-    for (u32 i = threadIdx.x; i < np; i += blockDim.x) {
-      size_t slot = i == 0 ? 2 * (size_t)t0 + 1 : 2 * ((size_t)t0 + i);
+// Heavy buckets.  A work item is (queue entry, part): one part for an ordinary heavy bucket,
+// HEAVY_PARTS parts for a bucket with more than HEAVY_SPLIT_MIN partials (a 0/1 bit vector puts
+// 3/4 of all entries into one bucket).  The 64 quads of a workgroup each add a strided share of
+// the item's partials quad-cooperatively, then a 6-level tree through LDS.  A split bucket's part
+// results go to tmp[slot][part]; the workgroup that draws the last ticket adds them up.
+__device__ __forceinline__ void heavy_reduce(xyzz& acc, const xyzz_mem* __restrict__ src, u32 lo, u32 hi, u32 first_slot,
+                                             bool raw, xyzz_mem* sh) {
+  // partial index i -> slot: raw: src[i]; else slot 2*t0+1 for i = 0 and 2*(t0+i) after (first_slot = t0)
+  const u32 quad = threadIdx.x >> 2, role = threadIdx.x & 3u;
+  xyzz_set_inf(acc);
+  for (u32 i = lo + quad; i < hi; i += 64) {
+    size_t slot = raw ? (size_t)i : (i == 0 ? 2 * (size_t)first_slot + 1 : 2 * ((size_t)first_slot + i));
+    xyzz p, r;
+    xyzz_load(p, &src[slot]);
+    xyzz_add_quad(r, acc, p, role);
+    acc = r;
+  }
+  if (role == 0) xyzz_store(&sh[quad], acc);
+  __syncthreads();
+  for (u32 s = 32; s >= 1; s >>= 1) {
+    if (quad < s) {
       xyzz p, r;
-      xyzz_load(p, &partials[slot]);
-      xyzz_add(r, acc, p);
+      xyzz_load(p, &sh[quad + s]);
+      xyzz_add_quad(r, acc, p, role);
       acc = r;
+      if (role == 0) xyzz_store(&sh[quad], acc);
     }
-    xyzz_store(&sh[threadIdx.x], acc);
     __syncthreads();
-    for (u32 s = 128; s >= 1; s >>= 1) {
-      if (threadIdx.x < s) {
-        xyzz p, r;
-        xyzz_load(p, &sh[threadIdx.x + s]);
-        xyzz_add(r, acc, p);
-        acc = r;
-        xyzz_store(&sh[threadIdx.x], acc);
-      }
+  }
+}
+__global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, u32 K, xyzz_mem* __restrict__ buckets,
+                                               const xyzz_mem* __restrict__ partials, u32* __restrict__ heavy_count,
+                                               const u32* __restrict__ heavy_list, xyzz_mem* __restrict__ tmp) {
+  __shared__ xyzz_mem sh[64];
+  __shared__ u32 ticket;
+  const u32 nheavy = heavy_count[0];
+  u32* tickets = heavy_count + 2;
+  // items are part-major (part 0 of every entry first) so that ordinary heavy buckets spread over
+  // all workgroups; parts >= 1 exist only when some bucket was split
+  const u32 nitems = nheavy * (heavy_count[1] ? HEAVY_PARTS : 1u);
+  for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const u32 ent = heavy_list[item % nheavy], part = item / nheavy;
+    const bool split = (ent & 0x80000000u) != 0;
+    if (!split && part != 0) continue;  // uniform over the workgroup
+    const u32 b = split ? (ent & 0xfffffu) : ent, slot = (ent >> 20) & 0x7ffu;
+    const u32 t0 = offsets[b] / K, t1 = (offsets[b + 1] - 1) / K, np = t1 - t0 + 1;
+    xyzz acc;
+    if (!split) {
+      heavy_reduce(acc, partials, 0, np, t0, false, sh);
+      if (threadIdx.x == 0) xyzz_store(&buckets[b], acc);
       __syncthreads();
+      continue;
     }
-    if (threadIdx.x == 0) xyzz_store(&buckets[b], acc);
+    const u32 per = (np + HEAVY_PARTS - 1) / HEAVY_PARTS;
+    const u32 lo = part * per, hi = lo + per < np ? lo + per : np;
+    heavy_reduce(acc, partials, lo < np ? lo : np, hi, t0, false, sh);
+    if (threadIdx.x == 0) {
+      xyzz_store(&tmp[(size_t)slot * HEAVY_PARTS + part], acc);
+      __threadfence();
+      ticket = atomicAdd(&tickets[slot], 1u);
+    }
+    __syncthreads();
+    if (ticket == HEAVY_PARTS - 1) {  // every part of this bucket is in tmp
+      __threadfence();
+      heavy_reduce(acc, tmp + (size_t)slot * HEAVY_PARTS, 0, HEAVY_PARTS, 0, true, sh);
+      if (threadIdx.x == 0) xyzz_store(&buckets[b], acc);
+    }
     __syncthreads();
   }
 }
