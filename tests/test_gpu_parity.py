@@ -315,6 +315,15 @@ def test_two_pass_sort_matches_single_pass(monkeypatch):
                 s1, s2 = e1.fr_upload(raw), e2.fr_upload(raw)
                 r1 = e1.msm_fr(b1, 0, 1, n, s1)
                 assert r1 == e2.msm_fr(b2, 0, 1, n, s2) and r1 != INF
+                # degenerate vectors: no entry at all, and every entry in one bucket
+                for val in (0, 1, N_ORDER - 1, N_ORDER, (1 << 255) + 12345):
+                    raw = (val % (1 << 256)).to_bytes(32, "big") * n
+                    s1, s2 = e1.fr_upload(raw), e2.fr_upload(raw)
+                    r1, r2 = e1.msm_fr(b1, 0, 1, n, s1), e2.msm_fr(b2, 0, 1, n, s2)
+                    assert r1 == r2
+                    assert (r1 == INF) == (val % N_ORDER == 0)
+                    s1.free()
+                    s2.free()
             b1.free()
             b2.free()
     finally:
