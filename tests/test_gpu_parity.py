@@ -301,11 +301,14 @@ def test_two_pass_sort_matches_single_pass(monkeypatch):
     e2 = crypto_amd.Engine(0)
     try:
         for n, flags in (((1 << 18), 1), ((1 << 18) + 12345, 1), ((1 << 21) + 5000, 1), ((1 << 21) + 300000, 1),
-                         ((1 << 18), 0), ((1 << 19) + 777, 0)):
+                         ((1 << 18), 0), ((1 << 19) + 777, 0), ((1 << 20) + 10, 0)):
             b1 = e1.random_bases(0xE0, n, flags=flags)
             b2 = e2.random_bases(0xE0, n, flags=flags)
             v1, v2 = e1.fr_random(0xE1, n), e2.fr_random(0xE1, n)
             assert e1.msm_fr(b1, 0, 1, n, v1) == e2.msm_fr(b2, 0, 1, n, v2)
+            # stride-2 views of points and scalars (reducePoints / reduceVector halves), odd offsets
+            m = (n - 1) // 2
+            assert e1.msm_fr(b1, 1, 2, m, v1, 0, 2) == e2.msm_fr(b2, 1, 2, m, v2, 0, 2)
             if n == 1 << 18:  # with and without a table
                 bits = np.random.default_rng(1).integers(0, 2, size=n // 2, dtype=np.uint8)
                 arr = np.zeros((n, 32), dtype=np.uint8)
