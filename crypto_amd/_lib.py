@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbn256msm.so")
+LIB_PATH = os.environ.get("BN256MSM_LIB") or os.path.join(_HERE, "libbn256msm.so")  # override: A/B builds
 
 EXPORTS = [
     "bn256_ctx_create", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
