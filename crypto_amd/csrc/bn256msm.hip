@@ -438,7 +438,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
       scan(ghist, gbase, (size_t)G2 * nt2 + 1);
       HIPCHK(hipEventRecord(ctx->ev[2], s));
       hipLaunchKernelGGL(k_part<true>, dim3(nt2), dim3(1024), lds_part1, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
-                         (u32)sc_stride, G2, LB2, ibits, key_stride, (u32*)nullptr, (const u32*)gbase, rank);
+                         (u32)sc_stride, G2, LB2, ibits, key_stride, ghist, (const u32*)gbase, rank);
       hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)gbase, nt2,
                          (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval);
       // groups too large for LDS (skewed scalars): split over SORT2_S workgroups; no-ops otherwise

@@ -192,33 +192,39 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
 #define SORT2_CAP 36864u     // records of one group that pass B sorts inside LDS (144 KiB)
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 sc_stride,
-                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32* __restrict__ ghist,
+                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32* ghist,
                                                const u32* __restrict__ gbase, u32* __restrict__ rec) {
   // key = w * key_stride + |digit| - 1: key_stride = 0 with a table (one bucket set, the window is
   // kept in the record), nb without (one bucket set per window, the window is implied by the group)
   extern __shared__ u32 lds[];  // count: per-wave histograms [16][G];  scatter: cnt[G], cur[G], dst[G], stage[]
   const u32 tile = blockIdx.x, ntiles = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const u32 nz = SCATTER ? G : 16 * G;
-  for (u32 j = threadIdx.x; j < nz; j += blockDim.x) lds[j] = 0;
-  __syncthreads();
   u32* cnt = SCATTER ? lds : lds + wave * G;
   u32* cur = lds + G;
   u32* gdst = lds + 2 * G;
   u32* stage = lds + 3 * G;
-  if (SCATTER)  // this tile's destination of every group, fetched once (strided reads, all in flight together)
-    for (u32 j = threadIdx.x; j < G; j += blockDim.x) gdst[j] = gbase[(size_t)j * ntiles + tile];
   const u32 lo = tile * SORT2_TILE;
   const u32 hi = lo >= n ? lo : ((n - lo > SORT2_TILE) ? lo + SORT2_TILE : n);
   const u32 lmask = (1u << LB) - 1u;
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    u32 k[8];
-    scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
-    bool neg = scalar_reduce_signed(k);
-    u32 carry = 0;
-    for (u32 w = 0; w < W; w++) {
-      u32 mag, sign;
-      recode_digit(k, neg, w, c, carry, mag, sign);
-      if (mag != 0) atomicAdd(&cnt[(w * key_stride + mag - 1) >> LB], 1u);
+  if (SCATTER) {
+    // this tile's count (left in ghist by the count pass) and destination of every group, fetched
+    // once: strided reads, all in flight together
+    for (u32 j = threadIdx.x; j < G; j += blockDim.x) {
+      cnt[j] = ghist[(size_t)j * ntiles + tile];
+      gdst[j] = gbase[(size_t)j * ntiles + tile];
+    }
+  } else {
+    for (u32 j = threadIdx.x; j < 16 * G; j += blockDim.x) lds[j] = 0;
+    __syncthreads();
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      u32 k[8];
+      scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
+      bool neg = scalar_reduce_signed(k);
+      u32 carry = 0;
+      for (u32 w = 0; w < W; w++) {
+        u32 mag, sign;
+        recode_digit(k, neg, w, c, carry, mag, sign);
+        if (mag != 0) atomicAdd(&cnt[(w * key_stride + mag - 1) >> LB], 1u);
+      }
     }
   }
   __syncthreads();
