@@ -51,7 +51,8 @@ struct bn256_ctx {
   u32* h_pack;      // pinned
   size_t h_pack_cap;
   u32* d_err;
-  u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy)
+  u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy), then the
+                    // 1024 group totals of the two-pass sort: everything a pass needs zeroed, one memset
   u32* h_err;       // pinned
 };
 
@@ -109,7 +110,7 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipMalloc(&ctx->d_err, 256));
-  HIPCHK(hipMalloc(&ctx->d_heavy, (2 + HEAVY_SLOTS) * sizeof(u32)));
+  HIPCHK(hipMalloc(&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32)));
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
@@ -319,7 +320,8 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   const bool use_lds = (size_t)nb * 4 <= 128 * 1024;
   const size_t lds_bytes = (size_t)nb * 4;
   const u32 want_tiles = std::max<u32>(1, 256 / nsets);
-  // two-pass sort (kernels.cuh "two-pass sort"): 2^15 buckets per set, <= 16 windows, <= 1024 groups
+  // two-pass sort (kernels.cuh "two-pass sort"): 2^15 buckets per set, <= 16 windows, <= 1024 groups and
+  // <= 1024 tiles per pass (k_group_sort scans either with one thread each), groups
   // that average <= 2^15 records, and a record that fits 32 bits: (window, index, sign, low key
   // bits) with a table; (index, sign, low key bits) without (the group implies the window)
   u32 ibits = 0, wbits = 0;
@@ -334,20 +336,22 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
   };
   const u32 tiles2_max = tiles2_for(nmax);
-  const bool two_pass = nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 &&
+  const bool two_pass = nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
                         entries_max <= (unsigned long long)G2 * 32768 &&
                         (precomp ? wbits + ibits + 1 + LB2 <= 32 : ibits + 1 + LB2 <= 32);
-  const size_t lds_part0 = (size_t)16 * G2 * 4, lds_part1 = ((size_t)3 * G2 + (size_t)W * SORT2_TILE) * 4;
-  const size_t lds_gsort = ((size_t)(NH2 + 2) * (1u << LB2) + SORT2_CAP) * 4;
+  const size_t lds_part = ((size_t)2 * G2 + std::max<size_t>((size_t)16 * G2, SORT2_TCAP)) * 4;
+  const size_t lds_gsort = ((size_t)(NH2 + 1) * (1u << LB2) + 2048 + SORT2_CAP) * 4;
   if (two_pass) {
-    // records of pass A; also the per-tile histograms of a short last pass that falls back
-    if ((rc = ws_reserve(ctx, WS_RANK, std::max<size_t>(entries_max * 4, (size_t)nsets * want_tiles * nb * 4)))) return rc;
-    if ((rc = ws_reserve(ctx, WS_GBASE, ((size_t)G2 * tiles2_max + 1) * 4))) return rc;
+    // records of pass A (one SORT2_TCAP block per tile); also the per-tile histograms of a short last
+    // pass that falls back to the single-pass sort
+    if ((rc = ws_reserve(ctx, WS_RANK, std::max<size_t>((size_t)tiles2_max * SORT2_TCAP * 4,
+                                                        (size_t)nsets * want_tiles * nb * 4))))
+      return rc;
+    if ((rc = ws_reserve(ctx, WS_GBASE, (size_t)tiles2_max * (G2 + 1) * 4))) return rc;  // loc[tile][0..G]
     if ((rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nbt * SORT2_S + 1) * 4))) return rc;
     if (!ctx->lds_attr2_set) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_part, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
       ctx->lds_attr2_set = 1;
     }
   }
@@ -375,8 +379,8 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
   if ((rc = ws_reserve(ctx, WS_HEAVYTMP, (size_t)HEAVY_SLOTS * HEAVY_PARTS * sizeof(xyzz_mem)))) return rc;
-  const size_t ncount = two_pass ? std::max<size_t>(nbt + 1, (size_t)G2 * tiles2_max + 1) : nbt + 1;
-  const size_t nscan_max = two_pass ? std::max<size_t>(nscan, nblocks((size_t)G2 * tiles2_max + 1, SCAN_TILE)) : nscan;
+  const size_t ncount = nbt + 1;
+  const size_t nscan_max = nscan;
   if ((rc = ws_reserve(ctx, WS_COUNTS, ncount * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BLOCKSUM, (size_t)(nscan_max + 1) * 4))) return rc;
@@ -417,7 +421,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
     }
 
     HIPCHK(hipEventRecord(ctx->ev[0], s));
-    HIPCHK(hipMemsetAsync(heavy_count, 0, (2 + HEAVY_SLOTS) * sizeof(u32), s));
+    HIPCHK(hipMemsetAsync(heavy_count, 0, (2 + HEAVY_SLOTS + 1024) * sizeof(u32), s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
     const bool two = two_pass && n_ch >= ((size_t)1 << (precomp ? 18 : 19));  // below: fixed costs of the 2^9..2^10 groups dominate
@@ -428,26 +432,24 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
       hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(SCAN_BLOCK), 0, s, out, (u32)m, (const u32*)blocksum);
     };
     if (two) {
-      u32* ghist = counts;
-      u32* gbase = (u32*)ctx->ws[WS_GBASE];
+      u32* gtotal = heavy_count + 2 + HEAVY_SLOTS;
+      u32* loc = (u32*)ctx->ws[WS_GBASE];
       u32* subhist = (u32*)ctx->ws[WS_SUBHIST];
       const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
-      hipLaunchKernelGGL(k_part<false>, dim3(nt2), dim3(1024), lds_part0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
-                         (u32)sc_stride, G2, LB2, ibits, key_stride, ghist, (const u32*)nullptr, (u32*)nullptr);
+      hipLaunchKernelGGL(k_part, dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, (u32)sc_stride, G2,
+                         LB2, ibits, key_stride, gtotal, loc, rank);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
-      scan(ghist, gbase, (size_t)G2 * nt2 + 1);
       HIPCHK(hipEventRecord(ctx->ev[2], s));
-      hipLaunchKernelGGL(k_part<true>, dim3(nt2), dim3(1024), lds_part1, s, sc_ch, (u32)n_ch, (u32)c, (u32)W,
-                         (u32)sc_stride, G2, LB2, ibits, key_stride, ghist, (const u32*)gbase, rank);
-      hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)gbase, nt2,
-                         (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval);
+      hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
+                         (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets,
+                         sval);
       // groups too large for LDS (skewed scalars): split over SORT2_S workgroups; no-ops otherwise
       hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), (size_t)4 * (1u << LB2) * 4, s, (const u32*)rank,
-                         (const u32*)gbase, nt2, TS, LB2, subhist);
-      hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(1024), 0, s, (const u32*)gbase, nt2, LB2, subhist, offsets);
+                         (const u32*)loc, (const u32*)gtotal, G2, TS, LB2, subhist);
+      hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(1024), 0, s, (const u32*)gtotal, LB2, subhist, offsets);
       hipLaunchKernelGGL(k_group_place, dim3(G2 * SORT2_S), dim3(256), (size_t)(1u << LB2) * 4, s, (const u32*)rank,
-                         (const u32*)gbase,
-                         (const u32*)subhist, nt2, TS, LB2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, sval);
+                         (const u32*)loc, (const u32*)gtotal, (const u32*)subhist, G2, TS, LB2, ibits, (u32)off_ch,
+                         (u32)stride, (u32)b->n, sval);
     } else {
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,

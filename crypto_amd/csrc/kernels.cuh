@@ -1,7 +1,7 @@
 // HIP kernels of the BN256 G1 MSM engine (gfx950).  Pipeline of one MSM
 // (vectorPointScalarMul, go/bp/util.go:165-175, go/bppp/util.go:178-196):
 //
-//   k_part<0/1>, k_group_sort   two-pass LDS-staged bucket sort (fixed-base, >= 2^18 points); otherwise:
+//   k_part, k_group_sort        two-pass LDS-staged bucket sort (fixed-base, >= 2^18 points); otherwise:
 //   k_tile_sort<0>    signed c-bit digits of every scalar, per-tile LDS bucket histograms
 //   k_tile_scan       per-bucket prefix over tiles;  k_scan1/2/3: bucket totals -> bucket offsets
 //   k_tile_sort<1>    LDS cursors, scatter of (base index|sign) into bucket order (counting sort)
@@ -170,113 +170,30 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
   }
 }
 
-// ------------------------------------------------------------------ two-pass sort (fixed-base, c = 16)
+// ------------------------------------------------------------------ two-pass sort (c = 16)
 // The single-pass scatter above writes every 4-byte entry to its own place in a 64 MiB array:
 // one 32-byte HBM sector per entry (PMC WRITE_SIZE 526 MB for 67 MB of entries), and even with
 // perfect merging in L2 one L2 write transaction per entry (~300 G/s: 54 us for 16.7 M entries).
-// With a table (one set of nb = 2^15 buckets) the sort is split in two passes that are both
-// staged through LDS so that every global store is a coalesced run:
-//   pass A  k_part<0>        tile of 2048 scalars -> counts per group (G = nb >> LB groups = high key
-//                            bits); scan over (group, tile)
-//           k_part<1>        same tile: counting sort by group inside LDS (<= 32768 records), then
-//                            each group's run is copied out contiguously.  record =
-//                            ((window, index, sign) << LB) | low key bits
-//   pass B  k_group_sort     one workgroup per group: counting sort of the group's records
-//                            (<= SORT2_CAP, all in LDS) by the low key bits, coalesced copy-out of
-//                            the final entries, and offsets[] for k_accumulate
-//   fallback for a group larger than SORT2_CAP (skewed scalars put nearly every entry into one
-//   group): k_group_count / k_group_subscan / k_group_place split the group over S workgroups with
+// With 2^15 buckets per set the sort is split in two passes, both staged through LDS so that
+// every global store is part of a long contiguous run:
+//   pass A  k_part         tile of 2048 scalars: recode once (records stay in registers), counting
+//                          sort by *group* (G = keys >> LB groups = high key bits) inside LDS, then
+//                          the tile's records go out as one contiguous block rec[tile][..] together
+//                          with the group boundaries loc[tile][0..G]; group totals by global atomics.
+//                          record = ((window, index, sign) << LB) | low key bits
+//   pass B  k_group_sort   one workgroup per group: gathers the group's run from every tile (a
+//                          contiguous ~256-byte read per tile), counting sort by the low key bits in
+//                          LDS, coalesced copy-out of the final entries, offsets[] for k_accumulate
+//   split path for a group larger than SORT2_CAP (skewed scalars put nearly every entry into one
+//   group): k_group_count / k_group_subscan / k_group_place spread the group over S workgroups with
 //   direct stores; they return at once for ordinary groups.
 #define SORT2_S 32u          // sub-parts per oversized group
 #define SORT2_TILE 2048u     // scalars per tile of pass A
-#define SORT2_CAP 36864u     // records of one group that pass B sorts inside LDS (144 KiB)
-template <bool SCATTER>
-__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 sc_stride,
-                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32* ghist,
-                                               const u32* __restrict__ gbase, u32* __restrict__ rec) {
-  // key = w * key_stride + |digit| - 1: key_stride = 0 with a table (one bucket set, the window is
-  // kept in the record), nb without (one bucket set per window, the window is implied by the group)
-  extern __shared__ u32 lds[];  // count: per-wave histograms [16][G];  scatter: cnt[G], cur[G], dst[G], stage[]
-  const u32 tile = blockIdx.x, ntiles = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  u32* cnt = SCATTER ? lds : lds + wave * G;
-  u32* cur = lds + G;
-  u32* gdst = lds + 2 * G;
-  u32* stage = lds + 3 * G;
-  const u32 lo = tile * SORT2_TILE;
-  const u32 hi = lo >= n ? lo : ((n - lo > SORT2_TILE) ? lo + SORT2_TILE : n);
-  const u32 lmask = (1u << LB) - 1u;
-  if (SCATTER) {
-    // this tile's count (left in ghist by the count pass) and destination of every group, fetched
-    // once: strided reads, all in flight together
-    for (u32 j = threadIdx.x; j < G; j += blockDim.x) {
-      cnt[j] = ghist[(size_t)j * ntiles + tile];
-      gdst[j] = gbase[(size_t)j * ntiles + tile];
-    }
-  } else {
-    for (u32 j = threadIdx.x; j < 16 * G; j += blockDim.x) lds[j] = 0;
-    __syncthreads();
-    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-      u32 k[8];
-      scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
-      bool neg = scalar_reduce_signed(k);
-      u32 carry = 0;
-      for (u32 w = 0; w < W; w++) {
-        u32 mag, sign;
-        recode_digit(k, neg, w, c, carry, mag, sign);
-        if (mag != 0) atomicAdd(&cnt[(w * key_stride + mag - 1) >> LB], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  if (!SCATTER) {
-    for (u32 j = threadIdx.x; j < G; j += blockDim.x) {
-      u32 t = 0;
-#pragma unroll
-      for (u32 v = 0; v < 16; v++) t += lds[v * G + j];
-      ghist[(size_t)j * ntiles + tile] = t;
-    }
-    if (tile == 0 && threadIdx.x == 0) ghist[(size_t)G * ntiles] = 0;  // sentinel: scan yields the total
-    return;
-  }
-  // exclusive scan of cnt[0..G) (G <= 1024 = blockDim) -> cur; stage[] is the scratch
-  const u32 j = threadIdx.x;
-  u32 own = j < G ? cnt[j] : 0;
-  stage[j] = own;
-  __syncthreads();
-  for (u32 d = 1; d < G; d <<= 1) {
-    u32 t = (j >= d) ? stage[j - d] : 0;
-    __syncthreads();
-    stage[j] += t;
-    __syncthreads();
-  }
-  if (j < G) cur[j] = stage[j] - own;
-  __syncthreads();
-  // second recode: place records by group inside LDS
-  for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    u32 k[8];
-    scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
-    bool neg = scalar_reduce_signed(k);
-    u32 carry = 0;
-    for (u32 w = 0; w < W; w++) {
-      u32 mag, sign;
-      recode_digit(k, neg, w, c, carry, mag, sign);
-      if (mag == 0) continue;
-      u32 key = w * key_stride + mag - 1;
-      u32 pos = atomicAdd(&cur[key >> LB], 1u);
-      u32 wfield = key_stride ? 0u : (w << ibits);
-      stage[pos] = ((((wfield | i) << 1) | sign) << LB) | (key & lmask);
-    }
-  }
-  __syncthreads();
-  // copy-out: group g's run (cur[g] now points past its end) goes to rec[gbase[g][tile] ...]
-  for (u32 g = wave; g < G; g += 16) {
-    u32 cn = cnt[g], src = cur[g] - cn, dst = gdst[g];
-    for (u32 t = lane; t < cn; t += 64) rec[dst + t] = stage[src + t];
-  }
-}
+#define SORT2_TCAP (16u * SORT2_TILE)  // record slots per tile (W <= 16 windows)
+#define SORT2_CAP 35840u     // records of one group that pass B sorts inside LDS (35 * 1024)
 
-// Exclusive scan of v over the first B (<= blockDim = 1024) threads through LDS scratch tmp[B..];
-// every thread of the block must call it.
+// Exclusive scan of v over the first B (<= blockDim = 1024) threads through LDS scratch tmp[0..B);
+// every thread of the block must call it.  tmp[j] holds the inclusive value afterwards.
 __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32 B, u32* tmp) {
   const u32 j = threadIdx.x;
   if (j < B) tmp[j] = v;
@@ -290,28 +207,128 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32 B, u32* tmp) {
   return j < B ? tmp[j] - v : 0;
 }
 
-// One workgroup per group: the group's records are rec[gbase[g*ntiles] .. gbase[(g+1)*ntiles]).
-// B = 2^LB keys per group (<= 512); NH histogram copies spread the LDS atomics.
-__global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec, const u32* __restrict__ gbase, u32 ntiles,
-                                                     u32 nbt, u32 LB, u32 NH, u32 ibits, u32 base_off, u32 pt_stride,
-                                                     u32 level_stride, u32* __restrict__ offsets, u32* __restrict__ sval) {
-  extern __shared__ u32 lds[];  // wcnt[NH][B], cur[B], tmp[B], stage[m]
-  const u32 B = 1u << LB, g = blockIdx.x, wave = threadIdx.x >> 6;
-  const u32 gs = gbase[(size_t)g * ntiles], ge = gbase[(size_t)(g + 1) * ntiles], m = ge - gs;
-  if (g == gridDim.x - 1 && threadIdx.x == 0) offsets[nbt] = ge;
-  if (m > SORT2_CAP) return;  // left to the split kernels below
+// key = w * key_stride + |digit| - 1: key_stride = 0 with a table (one bucket set, the window is
+// kept in the record), nb without (one bucket set per window, the window is implied by the group)
+__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 sc_stride,
+                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32* __restrict__ gtotal,
+                                               u32* __restrict__ loc, u32* __restrict__ rec) {
+  extern __shared__ u32 lds[];  // cnt[G], cur[G], then per-wave histograms [16][G] aliased by stage[TCAP]
+  const u32 tile = blockIdx.x, wave = threadIdx.x >> 6;
+  u32* cnt = lds;
+  u32* cur = lds + G;
+  u32* hist = lds + 2 * G;
+  u32* stage = hist;
+  for (u32 j = threadIdx.x; j < 16 * G; j += blockDim.x) hist[j] = 0;
+  __syncthreads();
+  const u32 lo = tile * SORT2_TILE;
+  const u32 hi = lo >= n ? lo : ((n - lo > SORT2_TILE) ? lo + SORT2_TILE : n);
+  const u32 lmask = (1u << LB) - 1u;
+  u32 rr[SORT2_TILE / 1024][16], gg[SORT2_TILE / 1024][16];
+#pragma unroll
+  for (u32 sidx = 0; sidx < SORT2_TILE / 1024; sidx++) {
+    const u32 i = lo + sidx * 1024 + threadIdx.x;
+    u32 k[8];
+    bool neg = false;
+    if (i < hi) {
+      scalar_load_be(k, scalars_be + (size_t)i * sc_stride * 32);
+      neg = scalar_reduce_signed(k);
+    }
+    u32 carry = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16; w++) {
+      gg[sidx][w] = 0xffffffffu;
+      rr[sidx][w] = 0;
+      if (i < hi && w < W) {
+        u32 mag, sign;
+        recode_digit(k, neg, w, c, carry, mag, sign);
+        if (mag != 0) {
+          u32 key = w * key_stride + mag - 1, grp = key >> LB;
+          u32 wfield = key_stride ? 0u : (w << ibits);
+          rr[sidx][w] = ((((wfield | (i - 0u)) << 1) | sign) << LB) | (key & lmask);
+          gg[sidx][w] = grp;
+          atomicAdd(&hist[wave * G + grp], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  u32 t = 0;
+  if (threadIdx.x < G) {
+#pragma unroll
+    for (u32 v = 0; v < 16; v++) t += hist[v * G + threadIdx.x];
+    cnt[threadIdx.x] = t;
+    if (t) atomicAdd(&gtotal[threadIdx.x], t);
+  }
+  __syncthreads();  // every histogram read is done before stage[] (same memory) becomes the scan scratch
+  u32 excl = block_exclusive_scan(t, G, stage);
+  if (threadIdx.x < G) {
+    cur[threadIdx.x] = excl;
+    loc[(size_t)tile * (G + 1) + threadIdx.x] = excl;
+    if (threadIdx.x == G - 1) loc[(size_t)tile * (G + 1) + G] = excl + t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 sidx = 0; sidx < SORT2_TILE / 1024; sidx++) {
+#pragma unroll
+    for (u32 w = 0; w < 16; w++) {
+      if (gg[sidx][w] != 0xffffffffu) {
+        u32 pos = atomicAdd(&cur[gg[sidx][w]], 1u);
+        stage[pos] = rr[sidx][w];
+      }
+    }
+  }
+  __syncthreads();
+  const u32 m = cur[G - 1];  // end of the last group = number of records of the tile
+  u32* dst = rec + (size_t)tile * SORT2_TCAP;
+  for (u32 j = threadIdx.x; j < m; j += blockDim.x) dst[j] = stage[j];
+}
+
+// One workgroup per group.  B = 2^LB keys per group (<= 512); NH histogram copies spread the LDS
+// atomics.  LDS: wcnt[NH][B], cur[B], tmp[1024], tile_a[1024], stage[SORT2_CAP].
+__global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec, const u32* __restrict__ loc,
+                                                     const u32* __restrict__ gtotal, u32 ntiles, u32 nbt, u32 LB, u32 NH,
+                                                     u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
+                                                     u32* __restrict__ offsets, u32* __restrict__ sval) {
+  extern __shared__ u32 lds[];
+  __shared__ u32 sh_gs, sh_m;
+  const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   u32* wcnt = lds;
   u32* cur = lds + NH * B;
   u32* tmp = cur + B;
-  u32* stage = tmp + B;
+  u32* tile_a = tmp + 1024;
+  u32* stage = tile_a + 1024;
+  // group start = prefix of the group totals
+  u32 tot = threadIdx.x < G ? gtotal[threadIdx.x] : 0;
+  u32 pre = block_exclusive_scan(tot, G, tmp);
+  if (threadIdx.x == g) {
+    sh_gs = pre;
+    sh_m = tot;
+  }
+  if (g == G - 1 && threadIdx.x == G - 1) offsets[nbt] = pre + tot;
+  __syncthreads();
+  const u32 gs = sh_gs, m = sh_m;
+  if (m > SORT2_CAP) return;  // left to the split kernels below
+  // gather: the group's run of every tile, placed back to back in stage[]
+  u32 a = 0, len = 0;
+  if (threadIdx.x < ntiles) {
+    a = loc[(size_t)threadIdx.x * (G + 1) + g];
+    len = loc[(size_t)threadIdx.x * (G + 1) + g + 1] - a;
+    tile_a[threadIdx.x] = a;
+  }
+  u32 toff = block_exclusive_scan(len, ntiles, tmp);  // tmp[t] = end of tile t's run afterwards
+  (void)toff;
+  for (u32 t = wave; t < ntiles; t += 16) {
+    u32 end = tmp[t], beg = t ? tmp[t - 1] : 0, src = t * SORT2_TCAP + tile_a[t];
+    for (u32 j = lane; j < end - beg; j += 64) stage[beg + j] = rec[(size_t)src + j];
+  }
   for (u32 j = threadIdx.x; j < NH * B; j += blockDim.x) wcnt[j] = 0;
   __syncthreads();
-  // the thread's records stay in registers for both LDS passes (m <= SORT2_CAP = 36 * 1024)
+  // the thread's records move to registers for both LDS passes (m <= SORT2_CAP = 35 * 1024)
   u32 r[SORT2_CAP / 1024];
 #pragma unroll
   for (u32 it = 0; it < SORT2_CAP / 1024; it++) {
     u32 e = it * 1024 + threadIdx.x;
-    r[it] = e < m ? rec[gs + e] : 0u;
+    r[it] = e < m ? stage[e] : 0u;
   }
   const u32 hrow = (wave & (NH - 1)) * B;
 #pragma unroll
@@ -341,29 +358,38 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
   for (u32 e = threadIdx.x; e < m; e += blockDim.x) sval[gs + e] = stage[e];
 }
 
-// ---- split path for oversized groups.  Block (g, sp) owns the records of tiles [sp*TS, (sp+1)*TS).
-__global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ gbase,
-                                                     u32 ntiles, u32 TS, u32 LB, u32* __restrict__ subhist) {
+// ---- split path for oversized groups.  Block (g, sp) owns the group's runs of tiles [sp*TS, (sp+1)*TS).
+__global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ loc,
+                                                     const u32* __restrict__ gtotal, u32 G, u32 TS, u32 LB,
+                                                     u32* __restrict__ subhist) {
   extern __shared__ u32 lds[];  // h[4][B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S, wave = threadIdx.x >> 6;
-  if (gbase[(size_t)(g + 1) * ntiles] - gbase[(size_t)g * ntiles] <= SORT2_CAP) return;
+  if (gtotal[g] <= SORT2_CAP) return;
   for (u32 j = threadIdx.x; j < 4 * B; j += blockDim.x) lds[j] = 0;
   __syncthreads();
-  const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
-  for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&lds[wave * B + (rec[e] & (B - 1))], 1u);
+  for (u32 t = sp * TS; t < (sp + 1) * TS; t++) {
+    const u32 a = loc[(size_t)t * (G + 1) + g], e = loc[(size_t)t * (G + 1) + g + 1];
+    const u32* src = rec + (size_t)t * SORT2_TCAP;
+    for (u32 j = a + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&lds[wave * B + (src[j] & (B - 1))], 1u);
+  }
   __syncthreads();
   for (u32 b = threadIdx.x; b < B; b += blockDim.x)
     subhist[((size_t)g * B + b) * SORT2_S + sp] = lds[b] + lds[B + b] + lds[2 * B + b] + lds[3 * B + b];
 }
 // exclusive scan, in place, of an oversized group's B*S counters (bucket-major), offset by the group
 // start; one block of 1024 threads per group, thread b owns bucket b's S counters
-__global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ gbase, u32 ntiles, u32 LB,
-                                                        u32* __restrict__ subhist, u32* __restrict__ offsets) {
+__global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ gtotal, u32 LB, u32* __restrict__ subhist,
+                                                        u32* __restrict__ offsets) {
   __shared__ u32 tmp[1024];
-  const u32 B = 1u << LB, g = blockIdx.x, b = threadIdx.x;
-  const u32 gs = gbase[(size_t)g * ntiles];
-  if (gbase[(size_t)(g + 1) * ntiles] - gs <= SORT2_CAP) return;
+  __shared__ u32 sh_gs;
+  const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, b = threadIdx.x;
+  if (gtotal[g] <= SORT2_CAP) return;
+  u32 tot = b < G ? gtotal[b] : 0;
+  u32 pre = block_exclusive_scan(tot, G, tmp);
+  if (b == g) sh_gs = pre;
+  __syncthreads();
+  const u32 gs = sh_gs;
   u32* row = subhist + ((size_t)g * B + b) * SORT2_S;
   u32 t = 0;
   if (b < B)
@@ -379,24 +405,27 @@ __global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ 
     }
   }
 }
-__global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec, const u32* __restrict__ gbase,
-                                                     const u32* __restrict__ subscan, u32 ntiles, u32 TS, u32 LB,
-                                                     u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
-                                                     u32* __restrict__ sval) {
+__global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec, const u32* __restrict__ loc,
+                                                     const u32* __restrict__ gtotal, const u32* __restrict__ subscan,
+                                                     u32 G, u32 TS, u32 LB, u32 ibits, u32 base_off, u32 pt_stride,
+                                                     u32 level_stride, u32* __restrict__ sval) {
   extern __shared__ u32 cur[];  // [B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
-  if (gbase[(size_t)(g + 1) * ntiles] - gbase[(size_t)g * ntiles] <= SORT2_CAP) return;
+  if (gtotal[g] <= SORT2_CAP) return;
   for (u32 b = threadIdx.x; b < B; b += blockDim.x) cur[b] = subscan[((size_t)g * B + b) * SORT2_S + sp];
   __syncthreads();
-  const u32 lo = gbase[(size_t)g * ntiles + sp * TS], hi = gbase[(size_t)g * ntiles + (sp + 1) * TS];
   const u32 imask = (1u << ibits) - 1u;
-  for (u32 e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-    u32 r = rec[e];
-    u32 pos = atomicAdd(&cur[r & (B - 1)], 1u);
-    u32 v = r >> LB, idx = v >> 1;
-    u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & imask) * pt_stride;
-    sval[pos] = (tidx << 1) | (v & 1u);
+  for (u32 t = sp * TS; t < (sp + 1) * TS; t++) {
+    const u32 a = loc[(size_t)t * (G + 1) + g], e = loc[(size_t)t * (G + 1) + g + 1];
+    const u32* src = rec + (size_t)t * SORT2_TCAP;
+    for (u32 j = a + threadIdx.x; j < e; j += blockDim.x) {
+      u32 r = src[j];
+      u32 pos = atomicAdd(&cur[r & (B - 1)], 1u);
+      u32 v = r >> LB, idx = v >> 1;
+      u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & imask) * pt_stride;
+      sval[pos] = (tidx << 1) | (v & 1u);
+    }
   }
 }
 
