@@ -9,8 +9,15 @@ from . import _lib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbpamd.so")
 EXPORTS = ["bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
-           "bp_wnla_det", "bp_wnla_synthetic"]
+           "bp_wnla_det", "bp_wnla_synthetic", "bp_ac_det"]
 _bp = None
+
+
+class AcCircuit(C.Structure):
+    """bp_ac_circuit of include/bp_amd.h."""
+    _fields_ = [(k, C.c_int) for k in ("Nm", "Nl", "Nv", "Nw", "No", "K", "Fl", "Fm")] + \
+               [(k, C.c_char_p) for k in ("Wm", "Wl", "Am", "Al", "v", "sv", "wl", "wr", "wo")] + \
+               [(k, C.POINTER(C.c_int32)) for k in ("f_lo", "f_ll", "f_lr", "f_no")]
 
 
 def load() -> C.CDLL:
@@ -28,6 +35,7 @@ def load() -> C.CDLL:
     lib.bp_wnla_det.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.POINTER(sz)]
     lib.bp_wnla_synthetic.argtypes = [vp, C.c_uint64, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int)]
+    lib.bp_ac_det.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(AcCircuit), C.c_char_p, sz, C.POINTER(sz)]
     lib.bp_keccak256.argtypes = [C.c_char_p, sz, C.c_char_p]
     lib.bp_last_error.restype = C.c_char_p
     _bp = lib
@@ -104,6 +112,75 @@ class WNLA:
         if rc not in (0, -21):
             raise RuntimeError(f"bp_wnla_synthetic rc={rc}: {self.lib.bp_last_error().decode()}")
         return {"ok": rc == 0, "ms_setup": ms0.value, "ms_run": ms1.value, "rounds": rounds.value}
+
+
+class ArithmeticCircuit:
+    """ArithmeticCircuitProtocol of go/bppp/docs_test.go:496-1240 over the device library
+    (bp_ac_det).  `pub` / `prv` are the dictionaries the oracle's ac_protocol takes, without the
+    generators (they come from the seeded reader): Nm, Nl, Nv, Nw, No, K, Wm, Wl, Am, Al, Fl, Fm and
+    v, sv, wl, wr, wo, f = {typ: [index or None]}."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.lib = load()
+
+    def run(self, seed: int, pre_draws: int, post_draws: int, pub: dict, prv: dict) -> dict:
+        n_order = 0x8fb501e34aa387f9aa6fecb86184dc212e8d8e12f82b39241a2ef45b57ac7261
+
+        def sc(xs):
+            return b"".join((int(x) % n_order).to_bytes(32, "big") for x in xs)
+
+        def flat(m):
+            return sc([x for row in m for x in row])
+
+        def fmap(typ, n):
+            return (C.c_int32 * n)(*[-1 if i is None else int(i) for i in prv["f"][typ][:n]])
+
+        keep = [fmap(1, pub["Nv"]), fmap(2, pub["Nv"]), fmap(3, pub["Nv"]), fmap(4, pub["Nm"])]
+        c = AcCircuit(pub["Nm"], pub["Nl"], pub["Nv"], pub["Nw"], pub["No"], pub["K"], int(bool(pub["Fl"])),
+                      int(bool(pub["Fm"])), flat(pub["Wm"]), flat(pub["Wl"]), sc(pub["Am"]), sc(pub["Al"]),
+                      flat(prv["v"]), sc(prv["sv"]), sc(prv["wl"]), sc(prv["wr"]), sc(prv["wo"]),
+                      C.cast(keep[0], C.POINTER(C.c_int32)), C.cast(keep[1], C.POINTER(C.c_int32)),
+                      C.cast(keep[2], C.POINTER(C.c_int32)), C.cast(keep[3], C.POINTER(C.c_int32)))
+        cap = 1 << 20
+        out = C.create_string_buffer(cap)
+        ln = C.c_size_t(0)
+        rc = self.lib.bp_ac_det(self.eng.ctx, seed, pre_draws, post_draws, C.byref(c), out, cap, C.byref(ln))
+        if rc not in (0, -21):
+            raise RuntimeError(f"bp_ac_det rc={rc}: {self.lib.bp_last_error().decode()}")
+        raw, pos = out.raw[:ln.value], 0
+
+        def pt():
+            nonlocal pos
+            pos += 64
+            return raw[pos - 64:pos].hex()
+
+        def u32():
+            nonlocal pos
+            pos += 4
+            return int.from_bytes(raw[pos - 4:pos], "big")
+
+        def frs():
+            nonlocal pos
+            k = u32()
+            v = [int.from_bytes(raw[pos + 32 * i:pos + 32 * i + 32], "big") for i in range(k)]
+            pos += 32 * k
+            return v
+
+        res = {"V": [pt() for _ in range(pub["K"])]}
+        for k in ("Co", "Cl", "Cr", "V_", "Cs", "PT", "CT"):
+            res[k] = pt()
+        res["check_V"], res["check_CT"], res["check_45"] = (bool(b) for b in raw[pos:pos + 3])
+        pos += 3
+        res["vT"] = int.from_bytes(raw[pos:pos + 32], "big")
+        pos += 32
+        res["lT"], res["nT"], res["cT"] = frs(), frs(), frs()
+        k = u32()
+        res["rounds"] = [(pt(), pt()) for _ in range(k)]
+        res["l"], res["n"] = frs(), frs()
+        res["wnla_ok"] = rc == 0
+        assert pos == len(raw)
+        return res
 
 
 def parse_proof(raw: bytes) -> dict:

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbn256msm.so")
 SOURCES = ["bn256msm.hip"]
-HEADERS = ["fe29.cuh", "fe_mul_gen.inc", "g1.cuh", "kernels.cuh", "host_g1.h", os.path.join("..", "..", "include", "bn256msm.h")]
+HEADERS = ["fe29.cuh", "fr.cuh", "fe_mul_gen.inc", "g1.cuh", "kernels.cuh", "host_g1.h", os.path.join("..", "..", "include", "bn256msm.h")]
 
 
 def _stale() -> bool:

@@ -905,6 +905,308 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
   }
 }
 
+// ------------------------------------------------------------------ go/bppp: arithmetic-circuit protocol
+// ArithmeticCircuitProtocol / InnerArithmeticCircuitProtocol2, go/bppp/docs_test.go:496-1240: every
+// commitment (Com, CommitOL, CommitR, Cs, PT, the C(t) checks) is one fused device MSM over the
+// resident HVec / GVec; the scalar algebra between them is host work on small vectors and dense
+// matrices, as in the reference.  Its debug prints (Wl*w, Eq. 34, the polynomial cross-checks)
+// produce no protocol value and are not restated.
+FrVec vectorAddPP(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:245-260
+  size_t n = std::max(a.size(), b.size());
+  return vectorAdd(padTo(a, n), padTo(b, n));
+}
+FrVec vectorSubPP(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:262-277
+  size_t n = std::max(a.size(), b.size());
+  return vectorSub(padTo(a, n), padTo(b, n));
+}
+FrVec powvector(const Fr& v, int n) {  // go/bppp/util.go:54-63
+  return n > 0 ? ntharr(v, n) : FrVec();
+}
+Fr fpow(const Fr& x, long y) {  // go/bppp/util.go:110-116
+  Fr b = y < 0 ? fr_inv(x) : x, acc = kFrOne;
+  unsigned long e = (unsigned long)(y < 0 ? -y : y);
+  for (; e; e >>= 1) {
+    if (e & 1) acc = mul(acc, b);
+    b = mul(b, b);
+  }
+  return acc;
+}
+FrVec vectorTensorMul(const FrVec& a, const FrVec& b) {  // go/bppp/util.go:134-141
+  FrVec r;
+  for (const Fr& y : b)
+    for (const Fr& x : a) r.push_back(mul(x, y));
+  return r;
+}
+typedef std::vector<FrVec> FrMat;
+FrVec vectorMulOnMatrix(const FrVec& a, const FrMat& m) {  // go/bppp/util.go:295-309
+  FrVec r;
+  for (size_t j = 0; j < m[0].size(); j++) {
+    FrVec col;
+    for (const FrVec& row : m) col.push_back(row[j]);
+    r.push_back(vectorMulPP(a, col));
+  }
+  return r;
+}
+FrMat diagInv(const Fr& x, int n) {  // go/bppp/util.go:321-340
+  FrMat r(n, FrVec(n, kFrZero));
+  Fr inv = fr_inv(x), val = inv;
+  for (int i = 0; i < n; i++) {
+    r[i][i] = val;
+    val = mul(val, inv);
+  }
+  return r;
+}
+FrVec concat(const FrVec& a, const FrVec& b) {
+  FrVec r(a);
+  r.insert(r.end(), b.begin(), b.end());
+  return r;
+}
+Fr neg(const Fr& x) { return sub(kFrZero, x); }  // minus(), go/bppp/util.go:76-78
+
+struct ACPublic {  // go/bppp/docs_test.go:12-30
+  int Nm, Nl, Nv, Nw, No, K;
+  Point G;
+  DevPoints GVec, HVec;
+  FrMat Wm, Wl;
+  FrVec Am, Al;
+  bool Fl, Fm;
+  std::vector<Point> V;
+};
+struct AcPrivate {  // go/bppp/docs_test.go:34-41; f tabulated: f[typ-1][j] = index into wo or -1
+  FrMat v;
+  FrVec sv, wl, wr, wo;
+  std::vector<int> f[4];
+};
+struct ACTranscript {
+  std::vector<Point> V;
+  Point Co, Cl, Cr, Vlin, Cs, PT, CT;
+  bool checkV, checkCT, check45;
+  Fr vT;
+  FrVec lT, nT, cT;
+  WnlaResult w;
+};
+// <HVec, a> + <GVec, b> with the BP++ vectorPointScalarMul rules, one device MSM
+Point comHG(bn256_ctx* ctx, const ACPublic& p, const FrVec& a, const FrVec& b) {
+  return msmStrided(ctx, {{&p.HVec, 0, 1, p.HVec.n, a}, {&p.GVec, 0, 1, p.GVec.n, b}});
+}
+// Com, go/bppp/docs_test.go:514-519
+Point Com(bn256_ctx* ctx, const FrVec& v, const Fr& s, const Point& G, const DevPoints& H) {
+  Point res = pointAdd(scalarMult(G, v[0]), scalarMult(H.at(0), s));
+  return pointAdd(res, msmStrided(ctx, {{&H, 9, 1, H.n > 9 ? H.n - 9 : 0, slice(v, 1, v.size())}}));
+}
+FrVec partitionOf(const AcPrivate& prv, int typ, int n) {  // docs_test.go:533-558, :579-586
+  FrVec r(n, kFrZero);
+  for (int j = 0; j < n; j++) {
+    int i = prv.f[typ - 1][j];
+    if (i >= 0) r[j] = prv.wo.at((size_t)i);
+  }
+  return r;
+}
+FrMat mappedColumns(const FrMat& W, const AcPrivate& prv, int typ, int n) {  // docs_test.go:652-759
+  FrMat r;
+  for (const FrVec& row : W) {
+    FrVec o(n, kFrZero);
+    for (int j = 0; j < n; j++) {
+      int i = prv.f[typ - 1][j];
+      if (i >= 0) o[j] = row.at((size_t)i);
+    }
+    r.push_back(o);
+  }
+  return r;
+}
+FrMat columns(const FrMat& W, size_t lo, size_t hi) {
+  FrMat r;
+  for (const FrVec& row : W) r.push_back(slice(row, lo, hi));
+  return r;
+}
+
+ACTranscript arithmeticCircuitProtocol(bn256_ctx* ctx, ACPublic& pub, const AcPrivate& prv, ByteStream* rd) {
+  ACTranscript T;
+  const int Nm = pub.Nm, Nl = pub.Nl, Nv = pub.Nv, K = pub.K;
+  const Fr two = fr_from_u64(2);
+  // :497-500
+  pub.V.clear();
+  for (int i = 0; i < K; i++) pub.V.push_back(Com(ctx, prv.v[i], prv.sv[i], pub.G, pub.HVec));
+  T.V = pub.V;
+  // CommitOL, :522-567
+  FrVec ro_ = valuesPP(rd, 7), rl_ = valuesPP(rd, 6);
+  FrVec ro = {ro_[0], ro_[1], ro_[2], ro_[3], kFrZero, ro_[4], ro_[5], ro_[6], kFrZero};
+  FrVec rl = {rl_[0], rl_[1], rl_[2], kFrZero, rl_[3], rl_[4], rl_[5], kFrZero, kFrZero};
+  FrVec nl = prv.wl;
+  FrVec no = partitionOf(prv, 4, Nm), lo = partitionOf(prv, 1, Nv), ll = partitionOf(prv, 2, Nv);
+  Point Co = comHG(ctx, pub, concat(ro, lo), no), Cl = comHG(ctx, pub, concat(rl, ll), nl);
+  // CommitR, :569-591
+  FrVec rr_ = valuesPP(rd, 5);
+  FrVec rr = {rr_[0], rr_[1], kFrZero, rr_[2], rr_[3], rr_[4], kFrZero, kFrZero, kFrZero};
+  FrVec nr = prv.wr, lr = partitionOf(prv, 3, Nv);
+  Point Cr = comHG(ctx, pub, concat(rr, lr), nr);
+  T.Co = Co;
+  T.Cl = Cl;
+  T.Cr = Cr;
+  // InnerArithmeticCircuitProtocol2, :593-1240
+  Fr ch_ro = valuesPP(rd, 1)[0], ch_lambda = valuesPP(rd, 1)[0], ch_beta = valuesPP(rd, 1)[0], ch_delta = valuesPP(rd, 1)[0];
+  FrMat MlnL = columns(pub.Wl, 0, Nm), MmnL = columns(pub.Wm, 0, Nm);
+  FrMat MlnR = columns(pub.Wl, Nm, 2 * Nm), MmnR = columns(pub.Wm, Nm, 2 * Nm);
+  FrMat WlO = columns(pub.Wl, 2 * Nm, pub.Wl.empty() ? 0 : pub.Wl[0].size());
+  FrMat WmO = columns(pub.Wm, 2 * Nm, pub.Wm.empty() ? 0 : pub.Wm[0].size());
+  FrMat MlnO = mappedColumns(WlO, prv, 4, Nm), MmnO = mappedColumns(WmO, prv, 4, Nm);
+  FrMat MllL = mappedColumns(WlO, prv, 2, Nv), MmlL = mappedColumns(WmO, prv, 2, Nv);
+  FrMat MllR = mappedColumns(WlO, prv, 3, Nv), MmlR = mappedColumns(WmO, prv, 3, Nv);
+  FrMat MllO = mappedColumns(WlO, prv, 1, Nv), MmlO = mappedColumns(WmO, prv, 1, Nv);
+
+  Fr ch_mu = mul(ch_ro, ch_ro);
+  const Fr bFl = pub.Fl ? kFrOne : kFrZero, bFm = pub.Fm ? kFrOne : kFrZero;
+  auto lcomb = [&](int i) {  // :778-783
+    return add(mul(bFl, fpow(ch_lambda, (long)Nv * i)), mul(bFm, fpow(ch_mu, (long)Nv * i + 1)));
+  };
+  // V_, :786-797
+  hostg1::Pt acc = hostg1::infinity();
+  for (int i = 0; i < K; i++) acc = hostg1::padd(acc, pt_load(scalarMult(pub.V[i], lcomb(i))));
+  Point V_ = scalarMult(pt_from(acc), two);
+  T.Vlin = V_;
+  // lambda, mu vectors, :800-809
+  FrVec lambda = vectorAddPP(
+      vectorTensorMul(vectorMulOnScalar(powvector(ch_lambda, Nv), ch_mu), powvector(fpow(ch_mu, Nv), K)),
+      vectorTensorMul(powvector(ch_mu, Nv), powvector(fpow(ch_lambda, Nv), K)));
+  lambda = vectorMulOnScalar(lambda, (pub.Fl && pub.Fm) ? kFrOne : kFrZero);
+  lambda = vectorSubPP(powvector(ch_lambda, Nl), lambda);
+  FrVec mu = vectorMulOnScalar(powvector(ch_mu, Nm), ch_mu);
+  // coefficients, :824-833
+  FrMat muDiagInv = diagInv(ch_mu, Nm);
+  auto cn = [&](const FrMat& Ml, const FrMat& Mm) {
+    return vectorMulOnMatrix(vectorSubPP(vectorMulOnMatrix(lambda, Ml), vectorMulOnMatrix(mu, Mm)), muDiagInv);
+  };
+  auto cl = [&](const FrMat& Ml, const FrMat& Mm) {
+    return vectorSubPP(vectorMulOnMatrix(lambda, Ml), vectorMulOnMatrix(mu, Mm));
+  };
+  FrVec cnL = cn(MlnL, MmnL), cnR = cn(MlnR, MmnR), cnO = cn(MlnO, MmnO);
+  FrVec clL = cl(MllL, MmlL), clR = cl(MllR, MmlR), clO = cl(MllO, MmlO);
+  // :836-879
+  FrVec ls = valuesPP(rd, Nv), ns = valuesPP(rd, Nm);
+  Fr v_ = kFrZero, rv1 = kFrZero;
+  FrVec v_1 = {kFrZero};
+  for (int i = 0; i < K; i++) {
+    v_ = add(v_, mul(prv.v[i][0], lcomb(i)));
+    rv1 = add(rv1, mul(prv.sv[i], lcomb(i)));
+    v_1 = vectorAddPP(v_1, vectorMulOnScalar(slice(prv.v[i], 1, prv.v[i].size()), lcomb(i)));
+  }
+  v_ = mul(v_, two);
+  FrVec rv(9, kFrZero);
+  rv[0] = mul(rv1, two);
+  v_1 = vectorMulOnScalar(v_1, two);
+  // Check V_ correct, :882-886
+  T.checkV = pointEq(V_, pointAdd(scalarMult(pub.G, v_), comHG(ctx, pub, concat(rv, v_1), {})));
+  // :888-891
+  FrVec pl = powvector(ch_lambda, Nv), pm = powvector(ch_mu, Nv);
+  FrVec cl0 = vectorSubPP(vectorMulOnScalar(slice(pl, 1, pl.size()), bFl),
+                          vectorMulOnScalar(vectorMulOnScalar(slice(pm, 1, pm.size()), ch_mu), bFm));
+  // f'(T), :894-936 (f_[3] is printed only)
+  const Fr d = ch_delta, dinv = fr_inv(ch_delta), twod = mul(two, d), twodinv = mul(two, dinv);
+  auto wv = [&](const FrVec& a, const FrVec& b) { return weightVectorMul(a, b, ch_mu); };
+  auto vm = [&](const FrVec& a, const FrVec& b) { return vectorMulPP(a, b); };
+  const FrVec nlR = vectorAddPP(nl, cnR), nrL = vectorAddPP(nr, cnL);
+  Fr fm2 = neg(wv(ns, ns));
+  Fr fm1 = add(vm(cl0, ls), mul(twod, wv(ns, no)));
+  Fr f0 = neg(mul(two, vm(clR, ls)));
+  f0 = sub(f0, mul(d, vm(cl0, lo)));
+  f0 = sub(f0, mul(wv(ns, nlR), two));
+  f0 = sub(f0, mul(mul(d, d), wv(no, no)));
+  Fr f1 = mul(two, vm(clL, ls));
+  f1 = add(f1, mul(two, mul(d, vm(clR, lo))));
+  f1 = add(f1, vm(cl0, ll));
+  f1 = add(f1, mul(wv(ns, nrL), two));
+  f1 = add(f1, mul(wv(no, nlR), twod));
+  Fr f2 = wv(cnR, cnR);
+  f2 = sub(f2, mul(two, mul(dinv, vm(clO, ls))));
+  f2 = sub(f2, mul(two, mul(d, vm(clL, lo))));
+  f2 = sub(f2, mul(two, vm(clR, ll)));
+  f2 = sub(f2, vm(cl0, lr));
+  f2 = sub(f2, mul(twodinv, wv(ns, cnO)));
+  f2 = sub(f2, mul(twod, wv(no, nrL)));
+  f2 = sub(f2, wv(nlR, nlR));
+  Fr f4 = mul(twodinv, wv(cnO, cnR));
+  f4 = add(f4, wv(cnL, cnL));
+  f4 = sub(f4, mul(twodinv, vm(clO, ll)));
+  f4 = sub(f4, mul(two, vm(clL, lr)));
+  f4 = sub(f4, mul(two, vm(clR, v_1)));
+  f4 = sub(f4, mul(twodinv, wv(nlR, cnO)));
+  f4 = sub(f4, wv(nrL, nrL));
+  Fr f5 = neg(mul(twodinv, wv(cnO, cnL)));
+  f5 = add(f5, mul(twodinv, vm(clO, lr)));
+  f5 = add(f5, mul(two, vm(clL, v_1)));
+  f5 = add(f5, mul(twodinv, wv(nrL, cnO)));
+  Fr f6 = neg(mul(twodinv, vm(clO, v_1)));
+  // rs, :984-998
+  const Fr binv = fr_inv(ch_beta);
+  FrVec rs = {
+      add(fm1, mul(ch_beta, mul(d, ro[1]))),
+      mul(fm2, binv),
+      mul(sub(add(f0, mul(d, ro[0])), mul(ch_beta, rl[1])), binv),
+      add(mul(sub(f1, rl[0]), binv), add(rr[1], mul(d, ro[2]))),
+      add(mul(add(f2, rr[0]), binv), sub(mul(d, ro[3]), rl[2])),
+      neg(mul(rv[0], binv)),
+      add(mul(f4, binv), add(mul(d, ro[5]), sub(rr[3], rl[4]))),
+      add(mul(f5, binv), sub(add(rr[4], mul(d, ro[6])), rl[5])),
+      add(mul(f6, binv), add(sub(mul(d, ro[7]), rl[6]), rr[5])),
+  };
+  Point Cs = comHG(ctx, pub, concat(rs, ls), ns);  // :1002-1003
+  T.Cs = Cs;
+  // :1009-1012
+  Fr t = valuesPP(rd, 1)[0], tinv = fr_inv(t), t2 = mul(t, t), t3 = mul(t2, t);
+  // l(T), :1038-1042
+  FrVec lT = vectorMulOnScalar(concat(rs, ls), tinv);
+  lT = vectorSubPP(lT, vectorMulOnScalar(concat(ro, lo), d));
+  lT = vectorAddPP(lT, vectorMulOnScalar(concat(rl, ll), t));
+  lT = vectorSubPP(lT, vectorMulOnScalar(concat(rr, lr), t2));
+  lT = vectorAddPP(lT, vectorMulOnScalar(concat(rv, v_1), t3));
+  // :1044-1050
+  FrVec pnT = vectorMulOnScalar(cnO, mul(dinv, t3));
+  pnT = vectorSubPP(pnT, vectorMulOnScalar(cnL, t2));
+  pnT = vectorAddPP(pnT, vectorMulOnScalar(cnR, t));
+  Fr psT = wv(pnT, pnT);
+  psT = add(psT, mul(two, mul(vm(lambda, pub.Al), t3)));
+  psT = sub(psT, mul(two, mul(vm(mu, pub.Am), t3)));
+  // :1069-1074
+  FrVec n_T = vectorMulOnScalar(ns, tinv);
+  n_T = vectorSubPP(n_T, vectorMulOnScalar(no, d));
+  n_T = vectorAddPP(n_T, vectorMulOnScalar(nl, t));
+  n_T = vectorSubPP(n_T, vectorMulOnScalar(nr, t2));
+  FrVec nT = vectorAddPP(pnT, n_T);
+  // PT, :1077-1078
+  Point PT = pointAdd(scalarMult(pub.G, psT), comHG(ctx, pub, {}, pnT));
+  T.PT = PT;
+  // :1080-1096, :1171
+  FrVec cr_T = {kFrOne, mul(ch_beta, tinv), mul(ch_beta, t), mul(ch_beta, t2), mul(ch_beta, t3),
+                mul(ch_beta, mul(t, t3)), mul(ch_beta, mul(t2, t3)), mul(ch_beta, mul(t3, t3)),
+                mul(ch_beta, mul(mul(t3, t), t3))};
+  FrVec cl_T = vectorMulOnScalar(clO, mul(t3, dinv));
+  cl_T = vectorSubPP(cl_T, vectorMulOnScalar(clL, t2));
+  cl_T = vectorAddPP(cl_T, vectorMulOnScalar(clR, t));
+  cl_T = vectorMulOnScalar(cl_T, two);
+  cl_T = vectorSubPP(cl_T, cl0);
+  FrVec cT = concat(cr_T, cl_T);
+  // CT, :1173-1179
+  Point CLeft = scalarMult(Cs, tinv);
+  CLeft = pointAdd(CLeft, scalarMult(Co, neg(d)));
+  CLeft = pointAdd(CLeft, scalarMult(Cl, t));
+  CLeft = pointAdd(CLeft, scalarMult(Cr, neg(t2)));
+  CLeft = pointAdd(CLeft, scalarMult(V_, t3));
+  Point CT = pointAdd(PT, CLeft);
+  T.CT = CT;
+  Fr vT = add(psT, mul(v_, t3));
+  T.vT = vT;
+  // Check C(t) = ComNormInnerArg(l, n, v), :1183-1189; Check (45), :1192-1203
+  T.checkCT = pointEq(CT, pointAdd(scalarMult(pub.G, vT), comHG(ctx, pub, lT, nT)));
+  T.check45 = pointEq(CLeft, pointAdd(scalarMult(pub.G, mul(v_, t3)), comHG(ctx, pub, lT, n_T)));
+  T.lT = lT;
+  T.nT = nT;
+  T.cT = cT;
+  // :1239
+  T.w = wnla(ctx, pub.G, cloneRange(ctx, pub.GVec), cloneRange(ctx, pub.HVec), DevFr(ctx, cT), CT, ch_ro, ch_mu,
+             DevFr(ctx, lT), DevFr(ctx, nT), rd);
+  return T;
+}
+
 thread_local std::string g_err;
 
 }  // namespace
@@ -1023,6 +1325,100 @@ extern "C" int bp_wnla_det(bn256_ctx* ctx, uint64_t seed, int nl, int nn, const 
     memcpy(out, o.data(), o.size());
     g_err = r.verified ? "" : "Failed to verify!";
     return r.verified ? 0 : BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}
+
+// ArithmeticCircuitProtocol (go/bppp/docs_test.go:496-1240) on a caller-described circuit, with the
+// reader injected: `pre_draws` values are drawn first (TestAC3 / TestAC4 draw sv and e before their
+// generators), then G = points(1)[0], GVec = points(Nm), HVec = points(9 + Nv), then `post_draws`
+// values (TestACProtocol / TestArithmeticCircuit2 draw sv after them).
+// out: V[K] | Co Cl Cr V_ Cs PT CT | 3 check bytes (V_, C(t), Eq. 45) | vT | u32 |l(T)|, l(T).. |
+//      u32 |n(T)|, n(T).. | u32 |c(T)|, c(T).. | WNLA part as bp_wnla_det without its leading C
+extern "C" int bp_ac_det(bn256_ctx* ctx, uint64_t seed, int pre_draws, int post_draws, const bp_ac_circuit* c,
+                         uint8_t* out, size_t cap, size_t* out_len) {
+  try {
+    if (!ctx || !c || !out || !out_len) return BN256_EINVAL;
+    if (c->Nm < 1 || c->Nl < 1 || c->Nv < 1 || c->No < 0 || c->K < 1 || c->Nw != 2 * c->Nm + c->No) return BN256_EINVAL;
+    if (!c->Wm || !c->Wl || !c->Am || !c->Al || !c->v || !c->sv || !c->wl || !c->wr || (!c->wo && c->No) || !c->f_lo ||
+        !c->f_ll || !c->f_lr || !c->f_no)
+      return BN256_EINVAL;
+    ByteStream rd{seed};
+    valuesPP(&rd, pre_draws);
+    ACPublic pub;
+    pub.Nm = c->Nm; pub.Nl = c->Nl; pub.Nv = c->Nv; pub.Nw = c->Nw; pub.No = c->No; pub.K = c->K;
+    pub.Fl = c->Fl != 0;
+    pub.Fm = c->Fm != 0;
+    pub.G = points(ctx, rd, 1).at(0);
+    pub.GVec = points(ctx, rd, c->Nm);
+    pub.HVec = points(ctx, rd, 9 + c->Nv);
+    valuesPP(&rd, post_draws);
+    auto vec = [](const uint8_t* p, int n) {
+      FrVec r(n);
+      for (int i = 0; i < n; i++) r[i] = fr_from_be(p + 32 * (size_t)i);
+      return r;
+    };
+    auto mat = [&](const uint8_t* p, int rows, int cols) {
+      FrMat m;
+      for (int i = 0; i < rows; i++) m.push_back(vec(p + 32 * (size_t)i * cols, cols));
+      return m;
+    };
+    pub.Wm = mat(c->Wm, c->Nm, c->Nw);
+    pub.Wl = mat(c->Wl, c->Nl, c->Nw);
+    pub.Am = vec(c->Am, c->Nm);
+    pub.Al = vec(c->Al, c->Nl);
+    AcPrivate prv;
+    prv.v = mat(c->v, c->K, c->Nv);
+    prv.sv = vec(c->sv, c->K);
+    prv.wl = vec(c->wl, c->Nm);
+    prv.wr = vec(c->wr, c->Nm);
+    prv.wo = vec(c->wo, c->No);
+    const int32_t* fs[4] = {c->f_lo, c->f_ll, c->f_lr, c->f_no};
+    const int fn[4] = {c->Nv, c->Nv, c->Nv, c->Nm};
+    for (int k = 0; k < 4; k++)
+      for (int j = 0; j < fn[k]; j++) {
+        if (fs[k][j] >= c->No) return BN256_EINVAL;
+        prv.f[k].push_back(fs[k][j]);
+      }
+    ACTranscript T = arithmeticCircuitProtocol(ctx, pub, prv, &rd);
+    std::vector<uint8_t> o;
+    auto pt = [&](const Point& p) { o.insert(o.end(), p.b, p.b + 64); };
+    auto u32be = [&](uint32_t k) {
+      o.push_back((uint8_t)(k >> 24)); o.push_back((uint8_t)(k >> 16)); o.push_back((uint8_t)(k >> 8)); o.push_back((uint8_t)k);
+    };
+    auto frs = [&](const FrVec& v) {
+      u32be((uint32_t)v.size());
+      for (const Fr& x : v) {
+        uint8_t b[32];
+        fr_to_be(b, x);
+        o.insert(o.end(), b, b + 32);
+      }
+    };
+    for (const Point& p : T.V) pt(p);
+    for (const Point* p : {&T.Co, &T.Cl, &T.Cr, &T.Vlin, &T.Cs, &T.PT, &T.CT}) pt(*p);
+    o.push_back(T.checkV);
+    o.push_back(T.checkCT);
+    o.push_back(T.check45);
+    uint8_t b[32];
+    fr_to_be(b, T.vT);
+    o.insert(o.end(), b, b + 32);
+    frs(T.lT);
+    frs(T.nT);
+    frs(T.cT);
+    u32be((uint32_t)T.w.X.size());
+    for (size_t i = 0; i < T.w.X.size(); i++) {
+      pt(T.w.X[i]);
+      pt(T.w.R[i]);
+    }
+    frs(T.w.l);
+    frs(T.w.n);
+    *out_len = o.size();
+    if (o.size() > cap) return BN256_ELENGTH;
+    memcpy(out, o.data(), o.size());
+    g_err = T.w.verified ? "" : "Failed to verify!";
+    return T.w.verified ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
     return BP_EFAIL;

@@ -40,6 +40,38 @@ int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, const uint8
 int bp_wnla_det(bn256_ctx* ctx, uint64_t seed, int nl, int nn, const uint8_t* l_be, const uint8_t* n_be,
                 uint8_t* out, size_t cap, size_t* out_len);
 
+/* A circuit for bp_ac_det: ACPublic / AcPrivate of go/bppp/docs_test.go:12-41 flattened.  Scalars are
+ * 32-byte big-endian, matrices row-major.  The PartitionF (typ, index) -> *int is tabulated: f_lo[j],
+ * f_ll[j], f_lr[j] (j < Nv; typ 1, 2, 3) and f_no[j] (j < Nm; typ 4) hold the index into wo, or -1. */
+typedef struct {
+  int Nm, Nl, Nv, Nw, No, K;
+  int Fl, Fm;
+  const uint8_t* Wm; /* Nm x Nw */
+  const uint8_t* Wl; /* Nl x Nw */
+  const uint8_t* Am; /* Nm */
+  const uint8_t* Al; /* Nl */
+  const uint8_t* v;  /* K x Nv */
+  const uint8_t* sv; /* K */
+  const uint8_t* wl; /* Nm */
+  const uint8_t* wr; /* Nm */
+  const uint8_t* wo; /* No */
+  const int32_t* f_lo;
+  const int32_t* f_ll;
+  const int32_t* f_lr;
+  const int32_t* f_no;
+} bp_ac_circuit;
+
+/* ArithmeticCircuitProtocol -- go/bppp/docs_test.go:496-1240 (Com :514-519, CommitOL :522-567, CommitR
+ * :569-591, Cs :1002-1003, PT :1077-1078, C(t) :1173-1177, its three bytes.Equal checks, then wnla
+ * :1239) with the reader injected: pre_draws values, G, GVec[Nm], HVec[9+Nv], post_draws values, then
+ * the protocol's own draws in the reference's order.  Every vector commitment is a device MSM.
+ * out: V[K] | Co Cl Cr V_ Cs PT CT (64 B each) | 3 check bytes (V_, C(t), Eq. 45) | vT (32 B) |
+ *      u32 BE |l(T)|, l(T).. | u32 |n(T)|, n(T).. | u32 |c(T)|, c(T).. |
+ *      u32 rounds | (X, R) per round | u32 |l|, l.. | u32 |n|, n..   (the WNLA part)
+ * 0 = the final WNLA check passed, BP_EVERIFY = "Failed to verify!". */
+int bp_ac_det(bn256_ctx* ctx, uint64_t seed, int pre_draws, int post_draws, const bp_ac_circuit* c, uint8_t* out,
+              size_t cap, size_t* out_len);
+
 /* BASELINE.json configs[3] shape: the same argument over synthetic commitment vectors of length
  * nl / nn (e.g. 2^20); reports wall ms for set-up and for the rounds, and the round count. */
 int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_t nn, double* ms_setup, double* ms_run,

@@ -793,3 +793,272 @@ def wnla_setup_and_run(seed: int, l, n):
     C = add(C, vector_point_scalar_mul_bppp(G, n))
     ok, rounds, lf, nf = wnla(g, G, H, c, C, ro, mu, list(l), list(n), rd)
     return dict(C=C, rounds=rounds, l=lf, n=nf, ok=ok)
+
+
+# --------------------------------------------------------------------------------------
+# Bulletproofs++ arithmetic-circuit protocol, go/bppp/docs_test.go:496-1240: the commitment
+# path (Com, CommitOL, CommitR, V_, Cs, PT, CT, the three bytes.Equal checks, then wnla) with
+# the scalar algebra that feeds it.  The reference's debug prints (Wl*w, Eq. 34, the
+# polynomial cross-checks) produce no protocol value and are left out.
+# --------------------------------------------------------------------------------------
+def fpow(x, y):
+    """go/bppp/util.go:110-116."""
+    return pow(finv(x), -y, N) if y < 0 else pow(x % N, y, N)
+
+
+def vector_mul_on_matrix(a, m):
+    """go/bppp/util.go:295-309: a * M (vector of column inner products)."""
+    return [vector_mul_bppp(a, [row[j] for row in m]) for j in range(len(m[0]))]
+
+
+def matrix_mul_on_vector(a, m):
+    """go/bppp/util.go:311-319."""
+    return [vector_mul_bppp(a, row) for row in m]
+
+
+def diag_inv(x, n):
+    """go/bppp/util.go:321-340."""
+    inv = finv(x)
+    res, val = [[0] * n for _ in range(n)], inv
+    for i in range(n):
+        res[i][i] = val
+        val = fmul(val, inv)
+    return res
+
+
+def com_bppp(v, s, G, H):
+    """Com, go/bppp/docs_test.go:514-519."""
+    res = mul(v[0] % N, G)
+    res = add(res, mul(s % N, H[0]))
+    return add(res, vector_point_scalar_mul_bppp(H[9:], v[1:]))
+
+
+def _partition(fmap, typ, n, wo):
+    """lo / ll / lr / no of CommitOL / CommitR (docs_test.go:533-558, 579-586): fmap[typ][j] is the
+    index into wo that the PartitionF returns for (typ, j), or None."""
+    out = []
+    for j in range(n):
+        i = fmap[typ][j]
+        out.append(0 if i is None else wo[i] % N)
+    return out
+
+
+def commit_ol(pub, wo, wl, fmap, reader):
+    """CommitOL, go/bppp/docs_test.go:522-567."""
+    ro_ = values_bppp(reader, 7)
+    rl_ = values_bppp(reader, 6)
+    ro = [ro_[0], ro_[1], ro_[2], ro_[3], 0, ro_[4], ro_[5], ro_[6], 0]
+    rl = [rl_[0], rl_[1], rl_[2], 0, rl_[3], rl_[4], rl_[5], 0, 0]
+    nl = list(wl)
+    no = _partition(fmap, 4, pub["Nm"], wo)
+    lo = _partition(fmap, 1, pub["Nv"], wo)
+    ll = _partition(fmap, 2, pub["Nv"], wo)
+    Co = add(vector_point_scalar_mul_bppp(pub["HVec"], ro + lo), vector_point_scalar_mul_bppp(pub["GVec"], no))
+    Cl = add(vector_point_scalar_mul_bppp(pub["HVec"], rl + ll), vector_point_scalar_mul_bppp(pub["GVec"], nl))
+    return ro, rl, no, nl, lo, ll, Co, Cl
+
+
+def commit_r(pub, wo, wr, fmap, reader):
+    """CommitR, go/bppp/docs_test.go:569-591."""
+    rr_ = values_bppp(reader, 5)
+    rr = [rr_[0], rr_[1], 0, rr_[2], rr_[3], rr_[4], 0, 0, 0]
+    nr = list(wr)
+    lr = _partition(fmap, 3, pub["Nv"], wo)
+    Cr = add(vector_point_scalar_mul_bppp(pub["HVec"], rr + lr), vector_point_scalar_mul_bppp(pub["GVec"], nr))
+    return rr, nr, lr, Cr
+
+
+def ac_protocol(pub, prv, reader):
+    """ArithmeticCircuitProtocol + InnerArithmeticCircuitProtocol2, go/bppp/docs_test.go:496-1240.
+    pub: Nm, Nl, Nv, Nw, No, K, G, GVec, HVec, Wm, Wl, Am, Al, Fl, Fm.  prv: v (K x Nv), sv (K), wl,
+    wr, wo, f = {typ: [index or None per j]} for typ 1..4 (the PartitionF tabulated).
+    Returns the transcript as a dict (points as affine tuples / None)."""
+    Nm, Nl, Nv, K = pub["Nm"], pub["Nl"], pub["Nv"], pub["K"]
+    fmap = prv["f"]
+    V = [com_bppp(prv["v"][i], prv["sv"][i], pub["G"], pub["HVec"]) for i in range(K)]
+    ro, rl, no, nl, lo, ll, Co, Cl = commit_ol(pub, prv["wo"], prv["wl"], fmap, reader)
+    rr, nr, lr, Cr = commit_r(pub, prv["wo"], prv["wr"], fmap, reader)
+
+    ch_ro = values_bppp(reader, 1)[0]
+    ch_lambda = values_bppp(reader, 1)[0]
+    ch_beta = values_bppp(reader, 1)[0]
+    ch_delta = values_bppp(reader, 1)[0]
+
+    Wl, Wm = pub["Wl"], pub["Wm"]
+    MlnL = [row[:Nm] for row in Wl]
+    MmnL = [row[:Nm] for row in Wm]
+    MlnR = [row[Nm:2 * Nm] for row in Wl]
+    MmnR = [row[Nm:2 * Nm] for row in Wm]
+    WlO = [row[2 * Nm:] for row in Wl]
+    WmO = [row[2 * Nm:] for row in Wm]
+
+    def mapped(W, typ, n):  # docs_test.go:652-759
+        return [[0 if fmap[typ][j] is None else row[fmap[typ][j]] % N for j in range(n)] for row in W]
+
+    MlnO, MmnO = mapped(WlO, 4, Nm), mapped(WmO, 4, Nm)
+    MllL, MmlL = mapped(WlO, 2, Nv), mapped(WmO, 2, Nv)
+    MllR, MmlR = mapped(WlO, 3, Nv), mapped(WmO, 3, Nv)
+    MllO, MmlO = mapped(WlO, 1, Nv), mapped(WmO, 1, Nv)
+
+    ch_mu = fmul(ch_ro, ch_ro)
+    Fl, Fm = int(bool(pub["Fl"])), int(bool(pub["Fm"]))
+
+    def lcomb(i):  # :778-783
+        return fadd(fmul(Fl, fpow(ch_lambda, Nv * i)), fmul(Fm, fpow(ch_mu, Nv * i + 1)))
+
+    V_ = None  # :786-797
+    for i in range(K):
+        V_ = add(V_, mul(lcomb(i), V[i]))
+    V_ = mul(2, V_)
+
+    lam = vector_add_bppp(  # :800-806
+        vector_tensor_mul(vector_mul_on_scalar(powvector(ch_lambda, Nv), ch_mu), powvector(fpow(ch_mu, Nv), K)),
+        vector_tensor_mul(powvector(ch_mu, Nv), powvector(fpow(ch_lambda, Nv), K)))
+    lam = vector_mul_on_scalar(lam, Fl & Fm)
+    lam = vector_sub_bppp(powvector(ch_lambda, Nl), lam)
+    mu = vector_mul_on_scalar(powvector(ch_mu, Nm), ch_mu)  # :809
+
+    muDiagInv = diag_inv(ch_mu, Nm)  # :824-833
+    cnL = vector_mul_on_matrix(vector_sub_bppp(vector_mul_on_matrix(lam, MlnL), vector_mul_on_matrix(mu, MmnL)), muDiagInv)
+    cnR = vector_mul_on_matrix(vector_sub_bppp(vector_mul_on_matrix(lam, MlnR), vector_mul_on_matrix(mu, MmnR)), muDiagInv)
+    cnO = vector_mul_on_matrix(vector_sub_bppp(vector_mul_on_matrix(lam, MlnO), vector_mul_on_matrix(mu, MmnO)), muDiagInv)
+    clL = vector_sub_bppp(vector_mul_on_matrix(lam, MllL), vector_mul_on_matrix(mu, MmlL))
+    clR = vector_sub_bppp(vector_mul_on_matrix(lam, MllR), vector_mul_on_matrix(mu, MmlR))
+    clO = vector_sub_bppp(vector_mul_on_matrix(lam, MllO), vector_mul_on_matrix(mu, MmlO))
+
+    ls = values_bppp(reader, Nv)  # :836-837
+    ns = values_bppp(reader, Nm)
+
+    v_ = 0  # :840-851
+    for i in range(K):
+        v_ = fadd(v_, fmul(prv["v"][i][0], lcomb(i)))
+    v_ = fmul(v_, 2)
+    rv = [0] * 9  # :853-865
+    rv1 = 0
+    for i in range(K):
+        rv1 = fadd(rv1, fmul(prv["sv"][i], lcomb(i)))
+    rv[0] = fmul(rv1, 2)
+    v_1 = [0]  # :868-879
+    for i in range(K):
+        v_1 = vector_add_bppp(v_1, vector_mul_on_scalar(prv["v"][i][1:], lcomb(i)))
+    v_1 = vector_mul_on_scalar(v_1, 2)
+
+    check = add(mul(v_, pub["G"]), vector_point_scalar_mul_bppp(pub["HVec"], rv + v_1))  # :882-886
+    check_V = marshal(V_) == marshal(check)
+
+    cl0 = vector_sub_bppp(  # :888-891
+        vector_mul_on_scalar(powvector(ch_lambda, Nv)[1:], Fl),
+        vector_mul_on_scalar(vector_mul_on_scalar(powvector(ch_mu, Nv)[1:], ch_mu), Fm))
+
+    wv, vm, d, dinv = weight_vector_mul, vector_mul_bppp, ch_delta, finv(ch_delta)
+    two = 2
+    f_ = {k: 0 for k in range(-2, 7)}  # :894-946
+    f_[-2] = fsub(f_[-2], wv(ns, ns, ch_mu))
+    f_[-1] = fadd(f_[-1], vm(cl0, ls))
+    f_[-1] = fadd(f_[-1], fmul(fmul(two, d), wv(ns, no, ch_mu)))
+    f_[0] = fsub(f_[0], fmul(two, vm(clR, ls)))
+    f_[0] = fsub(f_[0], fmul(d, vm(cl0, lo)))
+    f_[0] = fsub(f_[0], fmul(wv(ns, vector_add_bppp(nl, cnR), ch_mu), two))
+    f_[0] = fsub(f_[0], fmul(fmul(d, d), wv(no, no, ch_mu)))
+    f_[1] = fadd(f_[1], fmul(two, vm(clL, ls)))
+    f_[1] = fadd(f_[1], fmul(two, fmul(d, vm(clR, lo))))
+    f_[1] = fadd(f_[1], vm(cl0, ll))
+    f_[1] = fadd(f_[1], fmul(wv(ns, vector_add_bppp(nr, cnL), ch_mu), two))
+    f_[1] = fadd(f_[1], fmul(wv(no, vector_add_bppp(nl, cnR), ch_mu), fmul(two, d)))
+    f_[2] = fadd(f_[2], wv(cnR, cnR, ch_mu))
+    f_[2] = fsub(f_[2], fmul(two, fmul(dinv, vm(clO, ls))))
+    f_[2] = fsub(f_[2], fmul(two, fmul(d, vm(clL, lo))))
+    f_[2] = fsub(f_[2], fmul(two, vm(clR, ll)))
+    f_[2] = fsub(f_[2], vm(cl0, lr))
+    f_[2] = fsub(f_[2], fmul(fmul(two, dinv), wv(ns, cnO, ch_mu)))
+    f_[2] = fsub(f_[2], fmul(fmul(two, d), wv(no, vector_add_bppp(nr, cnL), ch_mu)))
+    f_[2] = fsub(f_[2], wv(vector_add_bppp(nl, cnR), vector_add_bppp(nl, cnR), ch_mu))
+    f_[4] = fadd(f_[4], fmul(fmul(two, dinv), wv(cnO, cnR, ch_mu)))
+    f_[4] = fadd(f_[4], wv(cnL, cnL, ch_mu))
+    f_[4] = fsub(f_[4], fmul(fmul(two, dinv), vm(clO, ll)))
+    f_[4] = fsub(f_[4], fmul(two, vm(clL, lr)))
+    f_[4] = fsub(f_[4], fmul(two, vm(clR, v_1)))
+    f_[4] = fsub(f_[4], fmul(fmul(two, dinv), wv(vector_add_bppp(nl, cnR), cnO, ch_mu)))
+    f_[4] = fsub(f_[4], wv(vector_add_bppp(nr, cnL), vector_add_bppp(nr, cnL), ch_mu))
+    f_[5] = fsub(f_[5], fmul(fmul(two, dinv), wv(cnO, cnL, ch_mu)))
+    f_[5] = fadd(f_[5], fmul(fmul(two, dinv), vm(clO, lr)))
+    f_[5] = fadd(f_[5], fmul(two, vm(clL, v_1)))
+    f_[5] = fadd(f_[5], fmul(fmul(two, dinv), wv(vector_add_bppp(nr, cnL), cnO, ch_mu)))
+    f_[6] = fsub(f_[6], fmul(fmul(two, dinv), vm(clO, v_1)))
+    # f_[3] (:938-946) is printed only; it enters no commitment
+
+    binv = finv(ch_beta)  # :984-998
+    rs = [
+        fadd(f_[-1], fmul(ch_beta, fmul(d, ro[1]))),
+        fmul(f_[-2], binv),
+        fmul(fsub(fadd(f_[0], fmul(d, ro[0])), fmul(ch_beta, rl[1])), binv),
+        fadd(fmul(fsub(f_[1], rl[0]), binv), fadd(rr[1], fmul(d, ro[2]))),
+        fadd(fmul(fadd(f_[2], rr[0]), binv), fsub(fmul(d, ro[3]), rl[2])),
+        fsub(0, fmul(rv[0], binv)),
+        fadd(fmul(f_[4], binv), fadd(fmul(d, ro[5]), fsub(rr[3], rl[4]))),
+        fadd(fmul(f_[5], binv), fsub(fadd(rr[4], fmul(d, ro[6])), rl[5])),
+        fadd(fmul(f_[6], binv), fadd(fsub(fmul(d, ro[7]), rl[6]), rr[5])),
+    ]
+    Cs = add(vector_point_scalar_mul_bppp(pub["HVec"], rs + ls), vector_point_scalar_mul_bppp(pub["GVec"], ns))  # :1002-1003
+
+    t = values_bppp(reader, 1)[0]  # :1009-1012
+    tinv, t2 = finv(t), fmul(t, t)
+    t3 = fmul(t2, t)
+
+    lT = vector_mul_on_scalar(rs + ls, tinv)  # :1038-1042
+    lT = vector_sub_bppp(lT, vector_mul_on_scalar(ro + lo, d))
+    lT = vector_add_bppp(lT, vector_mul_on_scalar(rl + ll, t))
+    lT = vector_sub_bppp(lT, vector_mul_on_scalar(rr + lr, t2))
+    lT = vector_add_bppp(lT, vector_mul_on_scalar(rv + v_1, t3))
+
+    pnT = vector_mul_on_scalar(cnO, fmul(dinv, t3))  # :1044-1050
+    pnT = vector_sub_bppp(pnT, vector_mul_on_scalar(cnL, t2))
+    pnT = vector_add_bppp(pnT, vector_mul_on_scalar(cnR, t))
+    psT = wv(pnT, pnT, ch_mu)
+    psT = fadd(psT, fmul(two, fmul(vm(lam, pub["Al"]), t3)))
+    psT = fsub(psT, fmul(two, fmul(vm(mu, pub["Am"]), t3)))
+
+    n_T = vector_mul_on_scalar(ns, tinv)  # :1069-1074
+    n_T = vector_sub_bppp(n_T, vector_mul_on_scalar(no, d))
+    n_T = vector_add_bppp(n_T, vector_mul_on_scalar(nl, t))
+    n_T = vector_sub_bppp(n_T, vector_mul_on_scalar(nr, t2))
+    nT = vector_add_bppp(pnT, n_T)
+
+    PT = add(mul(psT, pub["G"]), vector_point_scalar_mul_bppp(pub["GVec"], pnT))  # :1077-1078
+
+    cr_T = [1, fmul(ch_beta, tinv), fmul(ch_beta, t), fmul(ch_beta, t2), fmul(ch_beta, t3),  # :1080-1096
+            fmul(ch_beta, fmul(t, t3)), fmul(ch_beta, fmul(t2, t3)), fmul(ch_beta, fmul(t3, t3)),
+            fmul(ch_beta, fmul(fmul(t3, t), t3))]
+    cl_T = vector_mul_on_scalar(clO, fmul(t3, dinv))
+    cl_T = vector_sub_bppp(cl_T, vector_mul_on_scalar(clL, t2))
+    cl_T = vector_add_bppp(cl_T, vector_mul_on_scalar(clR, t))
+    cl_T = vector_mul_on_scalar(cl_T, 2)
+    cl_T = vector_sub_bppp(cl_T, cl0)
+    cT = cr_T + cl_T  # :1171
+
+    CT = add(PT, mul(tinv, Cs))  # :1173-1177
+    CT = add(CT, mul(fsub(0, d), Co))
+    CT = add(CT, mul(t, Cl))
+    CT = add(CT, mul(fsub(0, t2), Cr))
+    CT = add(CT, mul(t3, V_))
+    vT = fadd(psT, fmul(v_, t3))  # :1179
+
+    CTPrv = add(mul(vT, pub["G"]), vector_point_scalar_mul_bppp(pub["HVec"], lT))  # :1183-1189
+    CTPrv = add(CTPrv, vector_point_scalar_mul_bppp(pub["GVec"], nT))
+    check_CT = marshal(CT) == marshal(CTPrv)
+
+    CLeft = mul(tinv, Cs)  # :1192-1203
+    CLeft = add(CLeft, mul(fsub(0, d), Co))
+    CLeft = add(CLeft, mul(t, Cl))
+    CLeft = add(CLeft, mul(fsub(0, t2), Cr))
+    CLeft = add(CLeft, mul(t3, V_))
+    CTRight = add(mul(fmul(v_, t3), pub["G"]), vector_point_scalar_mul_bppp(pub["HVec"], lT))
+    CTRight = add(CTRight, vector_point_scalar_mul_bppp(pub["GVec"], n_T))
+    check_45 = marshal(CLeft) == marshal(CTRight)
+
+    try:  # :1239
+        ok, rounds, lf, nf = wnla(pub["G"], list(pub["GVec"]), list(pub["HVec"]), cT, CT, ch_ro, ch_mu, lT, nT, reader)
+    except ValueError:
+        ok, rounds, lf, nf = False, None, None, None
+    return dict(V=V, Co=Co, Cl=Cl, Cr=Cr, V_=V_, Cs=Cs, PT=PT, CT=CT, check_V=check_V, check_CT=check_CT,
+                check_45=check_45, vT=vT, rs=rs, lT=lT, nT=nT, cT=cT, wnla_ok=ok, rounds=rounds, l=lf, n=nf)

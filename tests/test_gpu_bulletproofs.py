@@ -125,3 +125,74 @@ def test_strided_msm_and_ragged_fold(eng, orc):
         if i < no:
             w = orc.add(w, orc.mul(braw[128 * i + 64:128 * i + 128], 5))
         assert out[i] == w
+
+
+# ------------------------------------------------------------------ go/bppp: arithmetic-circuit protocol
+@pytest.fixture(scope="module")
+def ac(eng):
+    from crypto_amd.bp import ArithmeticCircuit
+    return ArithmeticCircuit(eng)
+
+
+def _ac_expected(tr):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_ac_golden
+    want = make_ac_golden.transcript_json(tr)
+    for k in ("vT",):
+        want[k] = int(want[k], 16)
+    for k in ("lT", "nT", "cT", "l", "n"):
+        want[k] = [int(x, 16) for x in want[k]]
+    want["rounds"] = [tuple(x) for x in want["rounds"]]
+    return want
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_ac_protocol_transcript_identical_to_fixture(ac, idx):
+    """ArithmeticCircuitProtocol (go/bppp/docs_test.go:496-1240) over the device library on the
+    reference's own test circuits (TestACProtocol, TestArithmeticCircuit2, TestAC3, TestAC4): every
+    commitment (V, Co, Cl, Cr, V_, Cs, PT, C(t)), the opened l(T), n(T), c(T), the three bytes.Equal
+    checks and the whole WNLA transcript equal the committed oracle transcript byte for byte."""
+    import json
+    import os
+    import ac_cases
+    with open(os.path.join(os.path.dirname(__file__), "golden", "bppp_ac.json")) as f:
+        gold = json.load(f)
+    name, pre, post, pub, prv = ac_cases.CASES[idx]()
+    got = ac.run(gold["seed"], pre, post, pub, prv)
+    want = dict(gold["cases"][name])
+    want["vT"] = int(want["vT"], 16)
+    for k in ("lT", "nT", "cT", "l", "n"):
+        want[k] = [int(x, 16) for x in want[k]]
+    want["rounds"] = [tuple(x) for x in want["rounds"]]
+    assert got == want
+    assert got["check_V"] and got["check_CT"] and got["check_45"] and got["wnla_ok"]
+
+
+def test_ac_protocol_wide_circuit_matches_oracle(ac):
+    """The TestAC3 construction with 96 digits (Nv = 208, HVec of 217 points, 7 WNLA rounds): the
+    commitments are real multi-segment MSMs; compared with the oracle run live."""
+    import bn256_ref as ref
+    import ac_cases
+    case = ac_cases.wide_lookup()
+    name, pre, post, pub, prv = case
+    pubg, prvg, rd = ac_cases.with_generators(case, 0xAC77)
+    want = _ac_expected(ref.ac_protocol(pubg, prvg, rd))
+    got = ac.run(0xAC77, pre, post, pub, prv)
+    assert got == want and got["wnla_ok"]
+
+
+def test_ac_protocol_wrong_witness_fails_like_the_oracle(ac):
+    import bn256_ref as ref
+    import ac_cases
+    case = ac_cases.test_ac_protocol()
+    name, pre, post, pub, prv = case
+    prv = dict(prv)
+    prv["wo"] = [16]
+    bad = (name, pre, post, pub, prv)
+    pubg, prvg, rd = ac_cases.with_generators(bad, 0xAC00)
+    want = ref.ac_protocol(pubg, prvg, rd)
+    got = ac.run(0xAC00, pre, post, pub, prv)
+    assert got["check_CT"] == want["check_CT"] and got["wnla_ok"] == want["wnla_ok"] and not got["wnla_ok"]
+    assert got["CT"] == ref.marshal(want["CT"]).hex() and got["Co"] == ref.marshal(want["Co"]).hex()
