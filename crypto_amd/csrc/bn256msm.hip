@@ -274,6 +274,8 @@ extern "C" void bn256_bases_free(bn256_ctx* ctx, bn256_bases* b) {
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (bn256_ctx* lane : ctx->lane)  // a submitted call may still read the points
+      if (lane) (void)hipStreamSynchronize(lane->stream);
   }
   if (b->d) (void)hipFree(b->d);
   delete b;
@@ -357,7 +359,7 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
     return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
   };
   const u32 tiles2_max = tiles2_for(nmax);
-  const bool two_pass = nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
+  const bool two_pass = c == 16 && nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
                         entries_max <= (unsigned long long)G2 * 32768 &&
                         (precomp ? wbits + ibits + 1 + LB2 <= 32 : ibits + 1 + LB2 <= 32);
   const size_t lds_part = ((size_t)2 * G2 + std::max<size_t>((size_t)16 * G2, SORT2_TCAP)) * 4;
@@ -457,7 +459,7 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
       u32* loc = (u32*)ctx->ws[WS_GBASE];
       u32* subhist = (u32*)ctx->ws[WS_SUBHIST];
       const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
-      hipLaunchKernelGGL(k_part, dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, (u32)sc_stride, G2,
+      hipLaunchKernelGGL(k_part, dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W, (u32)sc_stride, G2,
                          LB2, ibits, key_stride, gtotal, loc, rank);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
       HIPCHK(hipEventRecord(ctx->ev[2], s));

@@ -192,27 +192,37 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
 #define SORT2_TCAP (16u * SORT2_TILE)  // record slots per tile (W <= 16 windows)
 #define SORT2_CAP 35840u     // records of one group that pass B sorts inside LDS (35 * 1024)
 
-// Exclusive scan of v over the first B (<= blockDim = 1024) threads through LDS scratch tmp[0..B);
-// every thread of the block must call it.  tmp[j] holds the inclusive value afterwards.
+// Exclusive scan of v over the first B (<= blockDim <= 1024) threads; every thread of the block must
+// call it.  Wave-level shuffles, then the 16 wave totals through LDS: two barriers in all.
+// tmp[j] (j < B) holds the inclusive value afterwards.
 __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32 B, u32* tmp) {
-  const u32 j = threadIdx.x;
-  if (j < B) tmp[j] = v;
-  __syncthreads();
-  for (u32 d = 1; d < B; d <<= 1) {
-    u32 t = (j < B && j >= d) ? tmp[j - d] : 0;
-    __syncthreads();
-    if (j < B) tmp[j] += t;
-    __syncthreads();
+  __shared__ u32 wsum[16];
+  const u32 j = threadIdx.x, lane = j & 63u, wave = j >> 6;
+  u32 x = j < B ? v : 0u;
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    u32 y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
   }
-  return j < B ? tmp[j] - v : 0;
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  u32 base = 0;
+  for (u32 w = 0; w < wave; w++) base += wsum[w];
+  x += base;
+  if (j < B) tmp[j] = x;
+  __syncthreads();
+  return j < B ? x - v : 0u;
 }
 
 // key = w * key_stride + |digit| - 1: key_stride = 0 with a table (one bucket set, the window is
 // kept in the record), nb without (one bucket set per window, the window is implied by the group)
-__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 sc_stride,
+// The window width is fixed at 16 bits (the only width with 2^15 buckets per set): with the window
+// loop unrolled every digit is a static half-word of the scalar, no dynamic word selects.
+__global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 W, u32 sc_stride,
                                                u32 G, u32 LB, u32 ibits, u32 key_stride, u32* __restrict__ gtotal,
                                                u32* __restrict__ loc, u32* __restrict__ rec) {
   extern __shared__ u32 lds[];  // cnt[G], cur[G], then per-wave histograms [16][G] aliased by stage[TCAP]
+  constexpr u32 c = 16;
   const u32 tile = blockIdx.x, wave = threadIdx.x >> 6;
   u32* cnt = lds;
   u32* cur = lds + G;

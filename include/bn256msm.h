@@ -70,7 +70,7 @@ int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, co
  * enqueued on one of BN256_ASYNC_LANES (2) internal lanes (own stream and workspaces), and wait blocks
  * for that lane, runs the host tail and returns the same bytes bn256_msm_dev would.  The bucket
  * reduction and host tail of one call then hide under the accumulation of the next (+9 % points/s at
- * 2^20 points).  The scalars must stay untouched until the matching wait; a third submit without a
+ * 2^20 points).  The scalars must stay untouched, and the bases handle alive, until the matching wait; a third submit without a
  * wait returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One thread per context, as
  * everywhere in this library. */
 int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
