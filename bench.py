@@ -9,7 +9,7 @@ A "step" is one complete MSM: every rank runs the device pipeline on its contigu
 2^log2n points (bases resident in HBM with their fixed-base table, scalars resident in HBM
 when the timed region starts), the 64-byte partial sums are exchanged with one RCCL
 all_gather, and every rank adds them on the host.  value = total points / second.
-Steps are issued through bn256_msm_submit / bn256_msm_wait with --depth (default 2) calls in
+Steps are issued through bn256_msm_submit / bn256_msm_wait with --depth (default 3) calls in
 flight, the way a prover issues its independent commitments (A and S, L and R): step i+1 is
 enqueued before step i's result is collected, and all K results are collected inside the timed
 region.  --depth 1 is the strictly blocking sequence; its rate is also reported
@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--no-precompute", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--depth", type=int, default=2, choices=[1, 2], help="MSM calls in flight per GPU")
+    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3], help="MSM calls in flight per GPU")
     args = ap.parse_args()
 
     import torch
@@ -72,8 +72,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 runs the multi-GPU code path (process group, all_gather of partials, barrier)
+    # with a single rank, to rehearse it on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import crypto_amd
@@ -89,42 +93,34 @@ def main():
     scalars = torch.empty(n * 32, dtype=torch.uint8, device=dev)
     eng.random_scalars_into(SEED_SCALARS, n, scalars.data_ptr(), first=first)
 
-    def finish(ticket):
-        p = eng.msm_wait(ticket)
-        if world == 1:
-            return p
-        return sharding.combine(sharding.all_gather_points(p, dev))
+    ex = sharding.AsyncExchange(world, dev) if use_dist else None
+    host_us = [0.0] * 3  # host time in submit / wait / exchange (start, finish of an older one, sum)
 
     def run(steps, depth, phase=None):
-        """steps MSMs with `depth` in flight; returns the last result.  Every result is collected
-        before this returns."""
-        q, res = [], None
-        for _ in range(steps):
-            q.append(eng.msm_submit(bases, scalars.data_ptr(), n))
-            if len(q) == depth:
-                res = finish(q.pop(0))
-                if phase is not None:
-                    phase[:] = [a + b for a, b in zip(phase, eng.last_timing())]
-        while q:
-            res = finish(q.pop(0))
+        def wait(ticket):
+            p = eng.msm_wait(ticket)
             if phase is not None:
                 phase[:] = [a + b for a, b in zip(phase, eng.last_timing())]
-        return res
+            return p
+
+        return sharding.run_pipelined(steps, depth, lambda: eng.msm_submit(bases, scalars.data_ptr(), n), wait, ex, host_us)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     run(args.depth, args.depth)  # set-up: every lane allocates its workspaces
     result = run(args.warmup, args.depth)
     sync()
+    host_us[:] = [0.0] * 3
     t0 = time.perf_counter()
     result = run(args.steps, args.depth)
     sync()
     dt = time.perf_counter() - t0
+    host_timed = [x / max(args.steps, 1) for x in host_us]
     # The same K steps as strictly blocking calls (not part of `value`).  The per-phase HIP events and
-    # the roofline's kernel time are taken here: with two calls in flight an event pair also spans
+    # the roofline's kernel time are taken here: with several calls in flight an event pair also spans
     # the time a kernel waits behind the other call's kernels, which is not kernel time.
     phase = [0.0] * 7
     t0 = time.perf_counter()
@@ -132,7 +128,7 @@ def main():
     sync()
     dt_blocking = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -175,6 +171,7 @@ def main():
             # per call, HIP events on the call's stream, over the K blocking calls that follow the timed region
             "phases_ms": {"sort_pass_a": phase[0], "scan": phase[1], "sort_pass_b": phase[2], "accumulate": phase[3],
                           "fix": phase[4], "reduce": phase[5], "device_total": phase[6]},
+            "host_us_per_step": {"submit": host_timed[0], "wait": host_timed[1], "exchange": host_timed[2]},
             "blocking_call": {"ms_per_call": dt_blocking / steps * 1e3, "points_per_s": n * world * args.steps / dt_blocking,
                               "same_result": bool(result_blocking == result)},
             "roofline": {
@@ -202,7 +199,7 @@ def main():
                           f"(per-term double-and-add + add, go/bp/util.go:165-175) restated in C, 1 thread",
             }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     eng.close()
 

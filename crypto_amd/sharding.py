@@ -47,13 +47,117 @@ class _Exchange:
         return [raw[64 * i:64 * i + 64] for i in range(self.world)]
 
 
+class AsyncExchange:
+    """The same exchange, split in start / finish so that it never stalls the host: while two MSM
+    calls are in flight the GPU is full (k_accumulate holds every wave slot for ~1 ms), an RCCL
+    kernel issued now is scheduled only when that kernel drains, and a host that waited for it could
+    not enqueue the next MSM in time.  start() enqueues copy-in, all_gather and copy-out on a side
+    stream and returns a ticket; finish() waits for that ticket's event -- one or two steps later,
+    when it has long completed.  `slots` exchanges may be outstanding."""
+
+    def __init__(self, world: int, device, slots: int = 4):
+        import torch
+        self.world, self.device, self.slots = world, device, slots
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        self.bufs = [_Exchange(world, device) for _ in range(slots)]
+        self.busy = [False] * slots
+        self.results: list = [None] * slots
+        if self.on_gpu:
+            self.stream = torch.cuda.Stream(device=device)
+            self.events = [torch.cuda.Event() for _ in range(slots)]
+
+    def start(self, part: bytes) -> int:
+        import torch
+        import torch.distributed as dist
+        if len(part) != 64:
+            raise ValueError("a marshalled G1 point is 64 bytes")
+        k = self.busy.index(False)  # ValueError when every slot is outstanding
+        ex = self.bufs[k]
+        if not self.on_gpu:
+            self.results[k] = ex.run(part)
+        else:
+            ex.h_in.numpy()[:] = memoryview(part)
+            with torch.cuda.stream(self.stream):
+                ex.d_in.copy_(ex.h_in, non_blocking=True)
+                work = dist.all_gather_into_tensor(ex.d_out, ex.d_in, async_op=True)
+                work.wait()  # orders the side stream after the collective; does not block the host
+                ex.h_out.copy_(ex.d_out, non_blocking=True)
+                self.events[k].record(self.stream)
+        self.busy[k] = True
+        return k
+
+    def finish(self, k: int) -> list[bytes]:
+        if not self.busy[k]:
+            raise ValueError("no exchange outstanding on this ticket")
+        self.busy[k] = False
+        if not self.on_gpu:
+            return self.results[k]
+        self.events[k].synchronize()
+        raw = self.bufs[k].h_out.numpy().tobytes()
+        return [raw[64 * i:64 * i + 64] for i in range(self.world)]
+
+
+def run_pipelined(steps: int, depth: int, submit, wait, ex=None, host_us=None):
+    """`steps` MSM calls with `depth` of them in flight (bn256_msm_submit / bn256_msm_wait through the
+    callables `submit() -> ticket`, `wait(ticket) -> 64-byte point`); returns the last result.  Every
+    result is collected -- and, when `ex` (an AsyncExchange) is given, exchanged between the ranks and
+    summed -- before this returns.  The exchange of step i is started right after the next submit
+    and finished when `depth` newer ones are outstanding, so the host neither delays the next call
+    nor waits for an RCCL kernel that queues behind a running accumulation.  depth = 1 is the
+    strictly blocking sequence: MSM, exchange, sum, next MSM.  `host_us` (3 floats) accumulates the
+    host microseconds spent in submit / wait / exchange."""
+    import time
+    q, xq, todo, res = [], [], [], None
+    host_us = host_us if host_us is not None else [0.0] * 3
+
+    def exchange(drain: bool = False):
+        nonlocal res
+        t1 = time.perf_counter()
+        while todo:
+            while len(xq) >= depth:  # at most `depth` exchanges outstanding
+                res = combine(ex.finish(xq.pop(0)))
+            xq.append(ex.start(todo.pop(0)))
+        while xq and (drain or depth == 1):
+            res = combine(ex.finish(xq.pop(0)))
+        host_us[2] += (time.perf_counter() - t1) * 1e6
+
+    def collect():
+        nonlocal res
+        t0 = time.perf_counter()
+        p = wait(q.pop(0))
+        host_us[1] += (time.perf_counter() - t0) * 1e6
+        if ex is None:
+            res = p
+        else:
+            todo.append(p)
+            if depth == 1:
+                exchange()
+
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        q.append(submit())
+        host_us[0] += (time.perf_counter() - t0) * 1e6
+        if ex is not None and depth > 1:
+            exchange()  # after the submit: the next call is enqueued before the host turns to the exchange
+        if len(q) == depth:
+            collect()
+    while q:
+        collect()
+    if ex is not None:
+        exchange(drain=True)
+    return res
+
+
 _exchanges: dict = {}
 
 
 def all_gather_points(part: bytes, device=None) -> list[bytes]:
     """Exchange one marshalled point per rank.  Returns world_size points (rank order)."""
+    import os
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return [part]
+    if dist.get_world_size() == 1 and not os.environ.get("BENCH_FORCE_DIST"):  # rehearsal switch of bench.py
         return [part]
     if len(part) != 64:
         raise ValueError("a marshalled G1 point is 64 bytes")

@@ -67,10 +67,10 @@ int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, co
  * (go/bp/main.go:89,95), L and R of an inner-product level (go/bp/main.go:340-341), the WNLA
  * round's X and R (go/bppp/docs_test.go:1312-1320) -- none of which needs another's result.  The reference computes
  * them one after the other on its single goroutine; here submit returns once the pipeline is
- * enqueued on one of BN256_ASYNC_LANES (2) internal lanes (own stream and workspaces), and wait blocks
+ * enqueued on one of 3 internal lanes (own stream and workspaces), and wait blocks
  * for that lane, runs the host tail and returns the same bytes bn256_msm_dev would.  The bucket
  * reduction and host tail of one call then hide under the accumulation of the next (+9 % points/s at
- * 2^20 points).  The scalars must stay untouched, and the bases handle alive, until the matching wait; a third submit without a
+ * 2^20 points).  The scalars must stay untouched, and the bases handle alive, until the matching wait; a fourth submit without a
  * wait returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One thread per context, as
  * everywhere in this library. */
 int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,

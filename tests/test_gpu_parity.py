@@ -354,7 +354,7 @@ def test_full_size_exact_answer(eng, orc, log2n, flags):
 
 
 def test_submit_wait_matches_blocking_calls(eng, orc):
-    """bn256_msm_submit / bn256_msm_wait (include/bn256msm.h): two commitments in flight at once
+    """bn256_msm_submit / bn256_msm_wait (include/bn256msm.h): several commitments in flight at once
     (A and S of go/bp/main.go:89,95 are independent) return exactly what two blocking calls return;
     sizes: the headline 2^20 with a table (closed form as the exact answer), a chunked 2^22 call,
     a small table-less one against the oracle's term loop, and the empty call."""
@@ -372,11 +372,13 @@ def test_submit_wait_matches_blocking_calls(eng, orc):
     for _ in range(3):  # lanes are reused; the second and third rounds run on warm workspaces
         ta = eng.msm_submit(h, a.data_ptr(), n)
         tb = eng.msm_submit(h, b.data_ptr(), n)
-        assert ta != tb
-        with pytest.raises(BN256Error) as ei:  # both lanes taken
+        tc = eng.msm_submit(h, a.data_ptr(), n)
+        assert len({ta, tb, tc}) == 3
+        with pytest.raises(BN256Error) as ei:  # all three lanes taken
             eng.msm_submit(h, a.data_ptr(), n)
         assert ei.value.code == -8
         assert eng.msm_wait(tb) == want_b  # any order
+        assert eng.msm_wait(tc) == want_a
         assert eng.msm_wait(ta) == want_a
     with pytest.raises(BN256Error):  # a ticket is good for one wait
         eng.msm_wait(ta)

@@ -34,7 +34,20 @@ def _worker(rank, world, port, n_total, q):
         part = orc.msm(bases, scal)
         parts = sharding.all_gather_points(part)
         total = sharding.combine(parts)
-        q.put((rank, off, n, total.hex(), [p.hex() for p in parts]))
+        # the start / finish form bench.py uses with two calls in flight: several exchanges
+        # outstanding, finished in order, same answers
+        ex = sharding.AsyncExchange(world, None, slots=3)
+        other = orc.msm(bases[:64 * (n - 1)], scal[:32 * (n - 1)])
+        t1, t2 = ex.start(part), ex.start(other)
+        async_ok = ex.finish(t1) == parts and sharding.combine(ex.finish(t1 if False else t2)) is not None
+        t3 = ex.start(part)
+        async_ok = async_ok and ex.finish(t3) == parts
+        try:
+            ex.finish(t3)
+            async_ok = False
+        except ValueError:
+            pass
+        q.put((rank, off, n, total.hex(), [p.hex() for p in parts], async_ok))
     finally:
         dist.destroy_process_group()
 
@@ -60,4 +73,56 @@ def test_two_rank_sharded_msm_matches_single():
     want = orc.msm(orc.synth_bases(0x5EED0001, n_total), orc.synth_scalars(0x5EED0002, n_total))
     assert res[0][3] == res[1][3] == want.hex()
     assert res[0][4] == res[1][4] and len(res[0][4]) == world
+    assert res[0][5] and res[1][5]
     assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 151, 151, 150)
+
+
+def test_run_pipelined_schedule():
+    """sharding.run_pipelined (the loop bench.py times) with stand-ins for the device and the exchange:
+    every step's result is collected and exchanged exactly once, in order; never more than `depth`
+    calls or exchanges outstanding; the last result is returned; depth 1 is strictly sequential."""
+    sys.path.insert(0, ROOT)
+    from crypto_amd import sharding
+
+    class FakeEx:
+        def __init__(self):
+            self.out, self.started, self.finished, self.max_out = {}, [], [], 0
+
+        def start(self, part):
+            k = len(self.started)
+            self.started.append(part)
+            self.out[k] = part
+            self.max_out = max(self.max_out, len(self.out))
+            return k
+
+        def finish(self, k):
+            self.finished.append(k)
+            return [self.out.pop(k)]
+
+    g0 = (1).to_bytes(32, "big") + (0x8fb501e34aa387f9aa6fecb86184dc21ee5b88d120b5b59e185cac6c5e089667 - 2).to_bytes(32, "big")
+    for depth in (1, 2, 3):
+        for steps in (0, 1, 2, 3, 7):
+            for with_ex in (False, True):
+                log, inflight, max_inflight = [], [], [0]
+                ex = FakeEx() if with_ex else None
+
+                def submit():
+                    t = sum(1 for e in log if e[0] == "s")
+                    log.append(("s", t))
+                    inflight.append(t)
+                    max_inflight[0] = max(max_inflight[0], len(inflight))
+                    return t
+
+                def wait(t):
+                    assert inflight.pop(0) == t
+                    log.append(("w", t))
+                    if ex is not None and depth == 1:
+                        assert len(ex.started) == len(ex.finished) == t  # strictly sequential
+                    return g0
+
+                res = sharding.run_pipelined(steps, depth, submit, wait, ex)
+                assert [e for e in log if e[0] == "w"] == [("w", t) for t in range(steps)]
+                assert not inflight and max_inflight[0] <= depth
+                assert res == (g0 if steps else None)
+                if ex is not None:
+                    assert ex.finished == list(range(steps)) and not ex.out and ex.max_out <= max(depth, 1)

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log2n", type=int, default=20)
 ap.add_argument("--threads", type=int, default=2)
 ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--delay-us", type=float, default=0.0, help="host busy-wait after every wait (submit/wait part)")
 a = ap.parse_args()
 n = 1 << a.log2n
 dev = torch.device("cuda", 0)
@@ -67,6 +68,9 @@ for depth in (1, 2):
             q.append(eng.msm_submit(bases, sc.data_ptr(), n))
             if len(q) == depth:
                 got.append(eng.msm_wait(q.pop(0)))
+                t_end = time.perf_counter() + a.delay_us * 1e-6
+                while time.perf_counter() < t_end:
+                    pass
         while q:
             got.append(eng.msm_wait(q.pop(0)))
         torch.cuda.synchronize()
