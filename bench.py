@@ -50,8 +50,8 @@ def cpu_baseline(sample_terms: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)

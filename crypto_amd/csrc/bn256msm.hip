@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -26,11 +28,91 @@ static void ctx_note_hip(hipError_t e, int line) {
   snprintf(g_hip_msg, sizeof g_hip_msg, "HIP error: %s (bn256msm.hip:%d)", hipGetErrorString(e), line);
 }
 
+// ---------------------------------------------------------------------------- handle memory
+// Handles (point sets, Fr vectors) come and go once per round in the provers' folding loops
+// (go/bp/main.go:355-358, go/bppp/docs_test.go:1318-1326): hipMalloc / hipFree cost 0.1 ms each and
+// hipFree waits for the whole device.  Freed blocks are therefore kept per device and handed out
+// again (smallest cached block between 1x and 4x the request); the cache is bounded and is released
+// when the last context of the process is destroyed.
+namespace pool {
+constexpr size_t kMaxCached = (size_t)8 << 30;
+struct Block {
+  void* p;
+  size_t cap;
+};
+static std::mutex g_mu;
+static std::multimap<size_t, void*> g_free[16];  // per device: capacity -> block
+static size_t g_cached[16];
+static int g_contexts;
+
+static hipError_t alloc(void** out, size_t bytes, size_t* cap, int* dev) {
+  int d = 0;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return e;
+  *dev = d;
+  bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  if (d >= 0 && d < 16) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_free[d].lower_bound(bytes);
+    if (it != g_free[d].end() && it->first <= 4 * bytes) {
+      *out = it->second;
+      *cap = it->first;
+      g_cached[d] -= it->first;
+      g_free[d].erase(it);
+      return hipSuccess;
+    }
+  }
+  *cap = bytes;
+  e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory && d >= 0 && d < 16) {  // give the cache back and try once more
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      for (auto& kv : g_free[d]) (void)hipFree(kv.second);
+      g_free[d].clear();
+      g_cached[d] = 0;
+    }
+    e = hipMalloc(out, bytes);
+  }
+  return e;
+}
+// The caller guarantees that no enqueued work still uses the block (every element-wise entry point
+// synchronises its stream before it returns; the free functions wait for submitted MSM calls).
+static void release(void* p, size_t cap, int dev) {
+  if (!p) return;
+  if (dev >= 0 && dev < 16) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_contexts > 0 && g_cached[dev] + cap <= kMaxCached) {
+      g_free[dev].emplace(cap, p);
+      g_cached[dev] += cap;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+static void context_created() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_contexts++;
+}
+static void context_destroyed() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (--g_contexts > 0) return;
+  for (int d = 0; d < 16; d++) {
+    if (g_free[d].empty()) continue;
+    (void)hipSetDevice(d);
+    for (auto& kv : g_free[d]) (void)hipFree(kv.second);
+    g_free[d].clear();
+    g_cached[d] = 0;
+  }
+}
+}  // namespace pool
+
 struct bn256_bases {
   aff_mem* d;     // [levels][n]
   size_t n;       // points per level
   int levels;     // 1, or W when precomputed
   int c;          // window bits the levels were built for (0 when levels == 1)
+  size_t cap;     // bytes of the block behind d (pool)
+  int dev;
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
@@ -120,6 +202,7 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
+  pool::context_created();
   *out = ctx;
   return BN256_OK;
 }
@@ -142,6 +225,7 @@ extern "C" void bn256_ctx_destroy(bn256_ctx* ctx) {
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  pool::context_destroyed();
   delete ctx;
 }
 
@@ -191,7 +275,7 @@ static bn256_bases* bases_alloc(size_t n, int levels, int c, int* rc) {
   b->c = c;
   b->d = nullptr;
   size_t bytes = std::max<size_t>(1, n) * (size_t)levels * sizeof(aff_mem);
-  hipError_t e = hipMalloc(&b->d, bytes);
+  hipError_t e = pool::alloc((void**)&b->d, bytes, &b->cap, &b->dev);
   if (e != hipSuccess) {
     ctx_note_hip(e, __LINE__);
     delete b;
@@ -269,15 +353,20 @@ extern "C" int bn256_bases_upload(bn256_ctx* ctx, const uint8_t* xy_be, size_t n
   return BN256_OK;
 }
 
+// A submitted MSM call (bn256_msm_submit) may still read the handle: wait for the lanes that hold one.
+static void wait_for_submitted(bn256_ctx* ctx) {
+  for (int i = 0; i < BN256_ASYNC_LANES; i++)
+    if (ctx->lane[i] && ctx->pending[i]) (void)hipStreamSynchronize(ctx->lane[i]->stream);
+}
+
 extern "C" void bn256_bases_free(bn256_ctx* ctx, bn256_bases* b) {
   if (!b) return;
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (bn256_ctx* lane : ctx->lane)  // a submitted call may still read the points
-      if (lane) (void)hipStreamSynchronize(lane->stream);
+    wait_for_submitted(ctx);
   }
-  if (b->d) (void)hipFree(b->d);
+  pool::release(b->d, b->cap, b->dev);
   delete b;
 }
 
@@ -982,6 +1071,8 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
 struct bn256_frvec {
   uint8_t* d;  // n x 32-byte big-endian scalars
   size_t n;
+  size_t cap;  // bytes of the block behind d (pool)
+  int dev;
 };
 
 static bn256_frvec* frvec_alloc(size_t n, int* rc) {
@@ -992,7 +1083,7 @@ static bn256_frvec* frvec_alloc(size_t n, int* rc) {
   }
   v->d = nullptr;
   v->n = n;
-  hipError_t e = hipMalloc((void**)&v->d, std::max<size_t>(n, 1) * 32);
+  hipError_t e = pool::alloc((void**)&v->d, std::max<size_t>(n, 1) * 32, &v->cap, &v->dev);
   if (e != hipSuccess) {
     ctx_note_hip(e, __LINE__);
     delete v;
@@ -1008,8 +1099,9 @@ extern "C" void bn256_fr_free(bn256_ctx* ctx, bn256_frvec* v) {
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    wait_for_submitted(ctx);
   }
-  if (v->d) (void)hipFree(v->d);
+  pool::release(v->d, v->cap, v->dev);
   delete v;
 }
 extern "C" size_t bn256_fr_len(const bn256_frvec* v) { return v ? v->n : 0; }
