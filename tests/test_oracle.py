@@ -216,3 +216,69 @@ def test_ac_protocol_rejects_a_wrong_witness():
     prv["wo"] = [16]
     tr = ref.ac_protocol(pub, prv, rd)
     assert not (tr["check_CT"] and tr["wnla_ok"])
+
+
+def test_curve_is_determined_by_the_group_order_the_reference_pins():
+    """The one curve constant the reference itself holds is the group order n
+    (go/bppp/docs_test.go:365-366, pinned above).  For a Barreto-Naehrig curve n fixes everything
+    else: n = 36u^4 + 36u^3 + 18u^2 + 6u + 1 has one positive integer root u, the field prime is
+    p = n + 6u^2, and y^2 = x^3 + b over F_p has prime order n for the BN choice of b.  So the
+    oracle's p is not an independent assumption, and since normalised affine coordinates are unique
+    any correct group law on this curve is byte-identical at Marshal() level."""
+    import random
+    n = ref.N
+    lo, hi = 0, 1 << 64
+    while lo < hi:  # integer root of the BN polynomial
+        u = (lo + hi) // 2
+        if 36 * u**4 + 36 * u**3 + 18 * u**2 + 6 * u + 1 < n:
+            lo = u + 1
+        else:
+            hi = u
+    u = lo
+    assert 36 * u**4 + 36 * u**3 + 18 * u**2 + 6 * u + 1 == n
+    assert u == 6518589491078791937                      # cloudflare/bn256's u (constants.go, from memory)
+    assert ref.P == n + 6 * u * u == 36 * u**4 + 36 * u**3 + 24 * u**2 + 6 * u + 1
+    assert ref.P % 4 == 3
+
+    def is_prime(m):  # Miller-Rabin, 40 fixed-seed bases
+        r, d = 0, m - 1
+        while d % 2 == 0:
+            r, d = r + 1, d // 2
+        rnd = random.Random(7)
+        for _ in range(40):
+            a = rnd.randrange(2, m - 1)
+            x = pow(a, d, m)
+            if x in (1, m - 1):
+                continue
+            for _ in range(r - 1):
+                x = x * x % m
+                if x == m - 1:
+                    break
+            else:
+                return False
+        return True
+
+    assert is_prime(n) and is_prime(ref.P)
+    # b = 3: the curve through G0 = (1, -2) has order n (not one of the five other twists' orders):
+    # n * Q = infinity for points found by try-and-increment, and the trace is t = p + 1 - n = 6u^2 + 1
+    assert ref.P + 1 - n == 6 * u * u + 1
+    rnd = random.Random(11)
+    found = 0
+    while found < 4:
+        x = rnd.randrange(ref.P)
+        rhs = (x * x * x + 3) % ref.P
+        y = pow(rhs, (ref.P + 1) // 4, ref.P)
+        if y * y % ref.P != rhs:
+            continue
+        found += 1
+        assert ref.mul(n, (x, y)) is ref.INF and ref.mul(n - 1, (x, y)) == (x, ref.P - y)
+    # b = 2 or 4 give other group orders: the order-n property singles out b = 3 among neighbours
+    for b in (2, 4):
+        while True:
+            x = rnd.randrange(ref.P)
+            rhs = (x * x * x + b) % ref.P
+            y = pow(rhs, (ref.P + 1) // 4, ref.P)
+            if y * y % ref.P == rhs:
+                break
+        # generic affine ladder on y^2 = x^3 + b (the doubling formula does not involve b)
+        assert ref.mul_affine_slow(n, (x, y)) is not ref.INF
