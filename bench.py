@@ -134,14 +134,17 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        traffic = None
+        traffic = executed = None
         try:  # HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (2^20, c=16 only)
             if args.log2n == 20 and not args.no_precompute and not args.window_bits:
                 with open(os.path.join(ROOT, "profiles", "r01_pmc_2p20.json")) as f:
                     pmc = json.load(f)["k_accumulate"]
                 traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
+                # executed work next to the canonical 23 120 IMAD/point ("report executed
+                # IMADs so waste is visible"): VALU lane-operations of all kinds per point
+                executed = pmc["SQ_INSTS_VALU"] * 64.0 / n
         except Exception:
-            traffic = None
+            traffic = executed = None
         phase = [p / steps for p in phase]
         acc_s = phase[3] * 1e-3
         achieved = n * IMAD_PER_POINT / acc_s if acc_s > 0 else 0.0
@@ -184,6 +187,7 @@ def main():
                 "unit": "IMAD/s",
                 "frac": achieved / IMAD_PEAK,
                 "traffic": traffic,
+                "executed_valu_lane_ops_per_point": executed,
                 "whole_msm_frac": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK,
             },
         }

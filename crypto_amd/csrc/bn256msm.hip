@@ -824,6 +824,9 @@ extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* 
 }
 
 // ---------------------------------------------------------------------------- element-wise
+// up to this many points a per-point scalar multiplication runs one quad per point (latency), above
+// it one lane per point (throughput): 2^14 quads are one wave per SIMD
+#define SCALAR_MUL_QUAD_MAX ((size_t)1 << 14)
 // Joint sparse form of (a mod n, b mod n); see jsf_arg in kernels.cuh.
 static void jsf_build(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg* out) {
   static const uint64_t nw[4] = {0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL, 0xaa6fecb86184dc21ULL,
@@ -900,8 +903,12 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
     if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) { bn256_bases_free(ctx, r); return rc; }
     hipError_t e = hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(in->d + off),
-                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
+      if (n <= SCALAR_MUL_QUAD_MAX)
+        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream,
+                           (const aff_mem*)(in->d + off), (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
+      else
+        hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(in->d + off),
+                           (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
       normalize_into(ctx, xs, r->d, n);
       e = hipStreamSynchronize(ctx->stream);
     }
@@ -1055,8 +1062,12 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
       hipLaunchKernelGGL(k_points_from_be, dim3(1), dim3(256), 0, ctx->stream, (const uint8_t*)tmp, d_g0, 1u, ctx->d_err);
       hipLaunchKernelGGL(k_synth_scalars, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
                          (uint8_t*)ctx->ws[WS_SCALARS], (u64)seed, (u64)first, (u32)n, 1u);
-      hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
-                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
+      if (n <= SCALAR_MUL_QUAD_MAX)
+        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
+                           (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
+      else
+        hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
+                           (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
       normalize_into(ctx, xs, b->d, n);
       e = hipStreamSynchronize(ctx->stream);
     }

@@ -963,6 +963,42 @@ __global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ 
   xyzz_store(&out[i], acc);
 }
 
+// The same for few points (the provers' small vectors: a call is one latency chain, not throughput
+// work): one quad per point, quad-cooperative doubling / addition, 2-bit windows over {P, 2P, 3P} --
+// 256 doublings + <= 128 additions in 3 + 4 multiplication stages each instead of 255 x (doubling +
+// addition) executed serially by one lane.
+__global__ void __launch_bounds__(256) k_scalar_mul_quad(const aff_mem* __restrict__ in,
+                                                         const uint8_t* __restrict__ scalars_be,
+                                                         xyzz_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
+                                                         u32 broadcast_point) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = gid >> 2, role = gid & 3u;
+  if (i >= n) return;  // whole quads leave together
+  fe x, y;
+  xyzz acc;
+  xyzz_set_inf(acc);
+  if (aff_load(x, y, &in[broadcast_point ? 0 : i], false)) {
+    u32 k[8];
+    scalar_load_be(k, scalars_be + (broadcast_scalar ? 0 : (size_t)i * 32));
+    bool neg = scalar_reduce_signed(k);
+    xyzz P1, P2, P3;
+    xyzz_from_affine(P1, x, fe_norm(neg ? fe_neg(y) : y));
+    xyzz_dbl_quad(P2, P1, role);
+    xyzz_add_quad(P3, P2, P1, role);
+    for (int w = 127; w >= 0; w--) {
+      xyzz t;
+      xyzz_dbl_quad(t, acc, role);
+      xyzz_dbl_quad(acc, t, role);
+      u32 d = (sel8(k, (u32)(2 * w) >> 5) >> ((2 * w) & 31)) & 3u;
+      if (d == 0) continue;  // uniform within the quad
+      xyzz T = d == 1 ? P1 : (d == 2 ? P2 : P3);
+      xyzz_add_quad(t, acc, T, role);
+      acc = t;
+    }
+  }
+  if (role == 0) xyzz_store(&out[i], acc);
+}
+
 __global__ void __launch_bounds__(256) k_add_points(const aff_mem* __restrict__ a, const aff_mem* __restrict__ b,
                                                     xyzz_mem* __restrict__ out, u32 n) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
