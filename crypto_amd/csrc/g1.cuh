@@ -120,7 +120,7 @@ __device__ __forceinline__ void xyzz_dbl_affine(xyzz& r, const fe& x, const fe& 
   fe s = fe_mul(x, v);
   fe m = fe_norm(fe_small_mul(fe_sqr(x), 3));
   fe x3 = fe_norm(fe_sub(fe_sub(fe_sqr(m), s), s));
-  fe y3 = fe_norm(fe_sub(fe_mul(m, fe_sub(s, x3)), fe_mul(w, y)));
+  fe y3 = fe_mul2add(m, fe_sub(s, x3), fe_neg(w), y);
   r.x = x3;
   r.y = y3;
   r.zz = v;
@@ -140,7 +140,7 @@ __device__ __forceinline__ void xyzz_dbl(xyzz& r, const xyzz& a) {
   fe s = fe_mul(a.x, v);
   fe m = fe_norm(fe_small_mul(fe_sqr(a.x), 3));
   fe x3 = fe_norm(fe_sub(fe_sub(fe_sqr(m), s), s));
-  fe y3 = fe_norm(fe_sub(fe_mul(m, fe_sub(s, x3)), fe_mul(w, a.y)));
+  fe y3 = fe_mul2add(m, fe_sub(s, x3), fe_neg(w), a.y);
   fe zz3 = fe_mul(v, a.zz);
   fe zzz3 = fe_mul(w, a.zzz);
   r.x = x3;
@@ -188,7 +188,8 @@ __device__ __forceinline__ void xyzz_madd(xyzz& acc, const fe& x2, const fe& y2)
   fe ppp = fe_mul(h, pp);
   fe q = fe_mul(acc.x, pp);
   fe x3 = fe_norm(fe_sub(fe_sub(fe_sub(fe_sqr(rr), ppp), q), q));
-  fe y3 = fe_norm(fe_sub(fe_mul(rr, fe_sub(q, x3)), fe_mul(acc.y, ppp)));
+  // rr (q - x3) - Y1 ppp under one reduction; |Y3| < 0.2p + p, limbs normalised by fe_mul2add
+  fe y3 = fe_mul2add(rr, fe_sub(q, x3), fe_neg(acc.y), ppp);
   acc.zz = fe_mul(acc.zz, pp);
   acc.zzz = fe_mul(acc.zzz, ppp);
   acc.x = x3;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) 
   fe ppp = fe_mul(h, pp);
   fe q = fe_mul(u1, pp);
   fe x3 = fe_norm(fe_sub(fe_sub(fe_sub(fe_sqr(rr), ppp), q), q));
-  fe y3 = fe_norm(fe_sub(fe_mul(rr, fe_sub(q, x3)), fe_mul(s1, ppp)));
+  fe y3 = fe_mul2add(rr, fe_sub(q, x3), fe_neg(s1), ppp);
   fe zz3 = fe_mul(fe_mul(a.zz, b.zz), pp);
   fe zzz3 = fe_mul(fe_mul(a.zzz, b.zzz), ppp);
   r.x = x3;
