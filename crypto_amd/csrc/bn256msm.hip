@@ -827,6 +827,24 @@ extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* 
 // up to this many points a per-point scalar multiplication runs one quad per point (latency), above
 // it one lane per point (throughput): 2^14 quads are one wave per SIMD
 #define SCALAR_MUL_QUAD_MAX ((size_t)1 << 14)
+// generator folds: one quad per output up to here (a single latency chain), one lane per output above
+static size_t fold_quad_max() {
+  static const size_t v = [] {
+    const char* e = getenv("BN256_FOLD_QUAD_MAX");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)28672;  // measured crossover: quad 1.0 ms at 2^14, 1.7 at 2^15; lane 1.6 flat to 2^16
+  }();
+  return v;
+}
+static void launch_fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32 stride, const jsf_arg& jsf,
+                               xyzz_mem* xs, u32 n_lo, u32 n_hi) {
+  const size_t n = std::max(n_lo, n_hi);
+  if (n <= fold_quad_max())
+    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf, xs,
+                       n_lo, n_hi);
+  else
+    hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf, xs, n_lo,
+                       n_hi);
+}
 // Joint sparse form of (a mod n, b mod n); see jsf_arg in kernels.cuh.
 static void jsf_build(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg* out) {
   static const uint64_t nw[4] = {0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL, 0xaa6fecb86184dc21ULL,
@@ -893,8 +911,7 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
     static const uint8_t zero[32] = {0};
     jsf_arg jsf;
     jsf_build(scalars_be, zero, &jsf);
-    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream,
-                       (const aff_mem*)(in->d + off), (const aff_mem*)(in->d + off), 1u, jsf, xs, (u32)n, 0u);
+    launch_fold_points(ctx, (const aff_mem*)(in->d + off), (const aff_mem*)(in->d + off), 1u, jsf, xs, (u32)n, 0u);
     normalize_into(ctx, xs, r->d, n);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
@@ -1000,8 +1017,7 @@ extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off,
     if ((rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
     jsf_arg jsf;
     jsf_build(s_lo_be, s_hi_be, &jsf);
-    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream,
-                       (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, jsf, xs,
+    launch_fold_points(ctx, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, jsf, xs,
                        (u32)n_lo, (u32)n_hi);
     normalize_into(ctx, xs, r->d, n);
     hipError_t e = hipStreamSynchronize(ctx->stream);

@@ -1077,6 +1077,70 @@ __global__ void __launch_bounds__(256) k_fold_points_quad(const aff_mem* __restr
   if (role == 0) xyzz_store(&out[i], acc);
 }
 
+// The same fold for many outputs (the first rounds of a 2^20-point WNLA / inner-product argument):
+// ONE LANE per output.  The quad kernel needs 256 VGPRs (one wave per SIMD, every multiplication
+// waits out its own latency) and spends 20 lane-multiplications per digit; here the chain is the
+// same joint sparse form, still without divergence (the digits are the grid's), at ~12
+// multiplications per digit and enough waves per SIMD to issue back to back.  P, Q stay affine
+// (mixed additions), P+Q and P-Q stay XYZZ (general additions).
+__global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
+                                                     u32 stride, jsf_arg jsf, xyzz_mem* __restrict__ out, u32 n_lo,
+                                                     u32 n_hi) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 n = n_lo > n_hi ? n_lo : n_hi;
+  if (i >= n) return;
+  // P+Q and P-Q live in LDS ([set][word][thread]: conflict-free), not in 72 more registers
+  __shared__ i32 sd[2][36][256];
+  fe px, py, qx, qy;
+  bool hp = i < n_lo && aff_load(px, py, &lo[(size_t)i * stride], false);
+  bool hq = i < n_hi && aff_load(qx, qy, &hi[(size_t)i * stride], false);
+  xyzz acc;
+#pragma unroll
+  for (int which = 0; which < 2; which++) {
+    xyzz_set_inf(acc);
+    if (hp) xyzz_from_affine(acc, px, py);
+    if (hq) xyzz_madd(acc, qx, which ? fe_neg(qy) : qy);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      sd[which][k][threadIdx.x] = acc.x.v[k];
+      sd[which][9 + k][threadIdx.x] = acc.y.v[k];
+      sd[which][18 + k][threadIdx.x] = acc.zz.v[k];
+      sd[which][27 + k][threadIdx.x] = acc.zzz.v[k];
+    }
+  }
+  xyzz_set_inf(acc);
+  for (int j = (int)jsf.len - 1; j >= 0; j--) {
+    {
+      xyzz t;
+      xyzz_dbl(t, acc);
+      acc = t;
+    }
+    u32 d = (jsf.w[j >> 3] >> ((j & 7) * 4)) & 15u;
+    if (d == 0) continue;  // uniform over the grid
+    u32 d0 = d & 3u, d1 = d >> 2;
+    bool neg = (d0 ? d0 : d1) == 3u;
+    if (d1 == 0) {
+      if (hp) xyzz_madd(acc, px, neg ? fe_neg(py) : py);
+    } else if (d0 == 0) {
+      if (hq) xyzz_madd(acc, qx, neg ? fe_neg(qy) : qy);
+    } else {
+      const u32 which = d0 == d1 ? 0u : 1u;
+      xyzz T, r;
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        T.x.v[k] = sd[which][k][threadIdx.x];
+        T.y.v[k] = sd[which][9 + k][threadIdx.x];
+        T.zz.v[k] = sd[which][18 + k][threadIdx.x];
+        T.zzz.v[k] = sd[which][27 + k][threadIdx.x];
+      }
+      if (neg) T.y = fe_neg(T.y);
+      xyzz_add(r, acc, T);
+      acc = r;
+    }
+  }
+  xyzz_store(&out[i], acc);
+}
+
 // out[i] = a_i * g + b_i * h: n independent 2-term Pedersen commitments with per-output scalars --
 // com() of go/bp/util.go:92-94 batched, and X[i] = x0[i]*GenH + x1[i]*GenG of go/ve-ca/main.go:37-40.
 // One quad per output, joint binary double-and-add over {g, h, g+h}; gh holds g, h (affine).

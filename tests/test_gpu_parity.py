@@ -209,6 +209,43 @@ def test_scalar_mul_batch_1024_vs_oracle(eng, orc):
     assert b"".join(eng.vector_point_mul_on_scalar(h, sc[0]).download()) == orc.scalar_mul_each(braw, sraw[:32], broadcast=True)
 
 
+def test_fold_lane_per_output_kernel(eng, orc):
+    """Generator folds of more than 28672 outputs run one lane per output (k_fold_points) instead of
+    one quad per output: the whole result against the quad kernel on <= 2^13-point pieces, edge cases
+    and a sample against the oracle (go/bp/main.go:355-356, vectorPointsAdd padding go/bppp/util.go:279-293)."""
+    n = (1 << 15) + 77
+    lo_raw = eng.random_bases(0xF01D, n).download()
+    hi_raw = eng.random_bases(0xF01E, n).download()
+    neg = lambda p: p[:32] + ((ref.P - int.from_bytes(p[32:], "big")) % ref.P).to_bytes(32, "big")  # noqa: E731
+    hi_raw[3] = lo_raw[3]        # P + P
+    hi_raw[5] = neg(lo_raw[5])   # P - P
+    lo_raw[7] = INF
+    hi_raw[9] = INF
+    lo_raw[11] = hi_raw[11] = INF
+    lo, hi = eng.upload(lo_raw), eng.upload(hi_raw)
+    s_lo = 0x1d0c0ffee << 190 | 12345
+    s_hi = N_ORDER - 0x77777777777
+    for a, b in ((s_lo, s_hi), (1, s_hi), (s_hi, s_hi), (s_lo, N_ORDER - s_lo)):
+        got = eng.fold(lo, 0, hi, 0, n, a, b).download()
+        want = []
+        for off in range(0, n, 1 << 13):
+            want += eng.fold(lo, off, hi, off, min(1 << 13, n - off), a, b).download()
+        assert got == want
+        for i in (0, 3, 5, 7, 9, 11, 64, 255, 256, 8191, 16384, 32768, n - 1):
+            assert got[i] == orc.add(orc.mul(lo_raw[i], a), orc.mul(hi_raw[i], b)), i
+    # ragged: the missing side counts as infinity
+    got = eng.fold2(lo, 0, n, hi, 0, n - 5, s_lo, s_hi).download()
+    assert got[:n - 5] == eng.fold(lo, 0, hi, 0, n, s_lo, s_hi).download()[:n - 5]
+    assert got[n - 5:] == eng.vector_point_mul_on_scalar(lo, s_lo, n - 5, 5).download()
+    # vectorPointMulOnScalar (go/bp/util.go:177-183) through the same kernel
+    got = eng.vector_point_mul_on_scalar(lo, s_hi).download()
+    want = []
+    for off in range(0, n, 1 << 13):
+        want += eng.vector_point_mul_on_scalar(lo, s_hi, off, min(1 << 13, n - off)).download()
+    assert got == want
+    assert got[100] == orc.mul(lo_raw[100], s_hi) and got[7] == INF
+
+
 @pytest.mark.parametrize("mode", ["plain", "precomp"])
 def test_skewed_scalar_distributions_65536(eng, orc, mode):
     """Bulletproofs-like scalars (go/bp/main.go:84-85: al in {0,1}, ar in {0,n-1}) and an
