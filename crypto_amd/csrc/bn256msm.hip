@@ -835,39 +835,30 @@ static size_t fold_quad_max() {
   }();
   return v;
 }
-static void launch_fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32 stride, const jsf_arg& jsf,
-                               xyzz_mem* xs, u32 n_lo, u32 n_hi) {
-  const size_t n = std::max(n_lo, n_hi);
-  if (n <= fold_quad_max())
-    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf, xs,
-                       n_lo, n_hi);
-  else
-    hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf, xs, n_lo,
-                       n_hi);
-}
-// Joint sparse form of (a mod n, b mod n); see jsf_arg in kernels.cuh.
-static void jsf_build(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg* out) {
+// k mod n for a 256-bit k (n > 2^255: one conditional subtraction), as five 64-bit words
+static void scalar_mod_n(uint64_t k[5], const uint8_t be[32]) {
   static const uint64_t nw[4] = {0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL, 0xaa6fecb86184dc21ULL,
                                  0x8fb501e34aa387f9ULL};
-  uint64_t k[2][5];
-  const uint8_t* src[2] = {a_be, b_be};
-  for (int s = 0; s < 2; s++) {
-    hostg1::be_load(k[s], src[s]);
-    k[s][4] = 0;
-    bool ge = true;
-    for (int i = 3; i >= 0; i--)
-      if (k[s][i] != nw[i]) { ge = k[s][i] > nw[i]; break; }
-    if (ge) {
-      unsigned __int128 br = 0;
-      for (int i = 0; i < 4; i++) {
-        unsigned __int128 d = (unsigned __int128)k[s][i] - nw[i] - (uint64_t)br;
-        k[s][i] = (uint64_t)d;
-        br = (d >> 64) & 1;
-      }
+  hostg1::be_load(k, be);
+  k[4] = 0;
+  bool ge = true;
+  for (int i = 3; i >= 0; i--)
+    if (k[i] != nw[i]) { ge = k[i] > nw[i]; break; }
+  if (ge) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) {
+      unsigned __int128 d = (unsigned __int128)k[i] - nw[i] - (uint64_t)br;
+      k[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
     }
   }
+}
+// Joint sparse form (Solinas) of (sa*ka, sb*kb) for magnitudes ka, kb (consumed) and signs sa, sb;
+// see jsf_arg in kernels.cuh.
+static void jsf_from_words(uint64_t k[2][5], bool neg_a, bool neg_b, jsf_arg* out) {
   memset(out, 0, sizeof *out);
   auto nonzero = [](const uint64_t* v) { return (v[0] | v[1] | v[2] | v[3] | v[4]) != 0; };
+  const bool neg[2] = {neg_a, neg_b};
   u32 len = 0;
   while (nonzero(k[0]) || nonzero(k[1])) {
     int u[2] = {0, 0};
@@ -887,12 +878,154 @@ static void jsf_build(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg* o
       }
       for (int i = 0; i < 4; i++) k[s][i] = (k[s][i] >> 1) | (k[s][i + 1] << 63);
       k[s][4] >>= 1;
+      if (neg[s]) u[s] = -u[s];
     }
     u32 nib = (u32)(u[0] == 0 ? 0 : (u[0] == 1 ? 1 : 3)) | ((u32)(u[1] == 0 ? 0 : (u[1] == 1 ? 1 : 3)) << 2);
     out->w[len >> 3] |= nib << ((len & 7) * 4);
     len++;
   }
   out->len = len;
+}
+// Joint sparse form of (a mod n, b mod n)
+static void jsf_build(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg* out) {
+  uint64_t k[2][5];
+  scalar_mod_n(k[0], a_be);
+  scalar_mod_n(k[1], b_be);
+  jsf_from_words(k, false, false, out);
+}
+
+// GLV decomposition for the latency-bound folds.  BN curves carry the endomorphism
+// phi(x, y) = (beta x, y) = lambda (x, y) (beta^3 = 1 in Fp, lambda^2 + lambda + 1 = 0 mod n;
+// FE_BETA_LIMBS in fe29.cuh), so k = k1 + k2 lambda with |k1|, |k2| < 2^129 and
+// k P = k1 P + phi(k2 P): two half-length chains that run side by side (k_fold_points_quad's
+// blockIdx.y).  Babai rounding against the reduced basis (A1, B1), (-B1, B2) of the lattice
+// {(x, y): x + y lambda = 0 mod n} (determinant n), with the quotients taken from 2^384 / n
+// reciprocals: c1 = floor(k B2 / n), c2 = floor(k B1 / n) up to one unit, which only moves
+// k1, k2 by one basis vector:  k1 = k - c1 A1 - c2 B1,  k2 = c2 B2 - c1 B1.
+// (lambda = 0x196ac037f07e9f9eecf9176e4f8bfcd513be518b5264ac23d; B1 = 2u + 1.)
+struct glv_half {
+  uint64_t m[5];  // magnitude
+  bool neg;
+};
+static void glv_split(const uint64_t k[5], glv_half* h1, glv_half* h2) {
+  static const uint64_t A1[2] = {0x6808727cb7be300bULL, 0xbfcdfabe288a7c7bULL};
+  static const uint64_t B1[1] = {0xb4ed5d35d8b10603ULL};
+  static const uint64_t B2[2] = {0xb31b1546df0d2a08ULL, 0xbfcdfabe288a7c7aULL};
+  static const uint64_t G1[5] = {0x60ee1bc8bdbf1528ULL, 0xe21d18f28a2a05c0ULL, 0xae13553c7c4a4445ULL,
+                                 0x55ae596cffd56e3dULL, 0x0000000000000001ULL};
+  static const uint64_t G2[4] = {0x369d86758c26a0b7ULL, 0x287e2fc7653eef7bULL, 0x424dd4af740d1660ULL,
+                                 0x0000000000000001ULL};
+  auto mul = [](uint64_t* r, int nr, const uint64_t* a, int na, const uint64_t* b, int nb) {
+    for (int i = 0; i < nr; i++) r[i] = 0;
+    for (int i = 0; i < na; i++) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < nb && i + j < nr; j++) {
+        c += (unsigned __int128)a[i] * b[j] + r[i + j];
+        r[i + j] = (uint64_t)c;
+        c >>= 64;
+      }
+      for (int t = i + nb; t < nr && c; t++) {
+        c += r[t];
+        r[t] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+  };
+  auto sub5 = [](uint64_t* r, const uint64_t* a) {  // r -= a, five words, two's complement
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 5; i++) {
+      unsigned __int128 d = (unsigned __int128)r[i] - a[i] - (uint64_t)br;
+      r[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
+    }
+  };
+  auto finish = [](glv_half* h, const uint64_t* v) {  // two's complement -> sign and magnitude
+    h->neg = (v[4] >> 63) != 0;
+    unsigned __int128 c = h->neg ? 1 : 0;
+    for (int i = 0; i < 5; i++) {
+      c += h->neg ? ~v[i] : v[i];
+      h->m[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  };
+  uint64_t t[10], c1[3], c2[3], u[5], v[5];
+  mul(t, 10, k, 4, G1, 5);
+  c1[0] = t[6]; c1[1] = t[7]; c1[2] = t[8];
+  mul(t, 10, k, 4, G2, 4);
+  c2[0] = t[6]; c2[1] = t[7]; c2[2] = 0;
+  // k1 = k - c1 A1 - c2 B1
+  uint64_t k1[5] = {k[0], k[1], k[2], k[3], 0};
+  mul(u, 5, c1, 3, A1, 2);
+  sub5(k1, u);
+  mul(u, 5, c2, 3, B1, 1);
+  sub5(k1, u);
+  // k2 = c2 B2 - c1 B1
+  mul(v, 5, c2, 3, B2, 2);
+  mul(u, 5, c1, 3, B1, 1);
+  sub5(v, u);
+  finish(h1, k1);
+  finish(h2, v);
+}
+// out[0]: joint sparse form of (a1, b1); out[1]: of (a2, b2), where a = a1 + a2 lambda, b = b1 + b2 lambda
+static void jsf_build_glv(const uint8_t a_be[32], const uint8_t b_be[32], jsf_arg out[2]) {
+  uint64_t ka[5], kb[5];
+  scalar_mod_n(ka, a_be);
+  scalar_mod_n(kb, b_be);
+  glv_half a[2], b[2];
+  glv_split(ka, &a[0], &a[1]);
+  glv_split(kb, &b[0], &b[1]);
+  for (int h = 0; h < 2; h++) {
+    uint64_t k[2][5];
+    memcpy(k[0], a[h].m, sizeof k[0]);
+    memcpy(k[1], b[h].m, sizeof k[1]);
+    jsf_from_words(k, a[h].neg, b[h].neg, &out[h]);
+  }
+}
+
+extern "C" int bn256_glv_split(const uint8_t k_be[32], uint8_t k1_be[32], int* k1_neg, uint8_t k2_be[32], int* k2_neg) {
+  if (!k_be || !k1_be || !k1_neg || !k2_be || !k2_neg) return BN256_EINVAL;
+  uint64_t k[5];
+  scalar_mod_n(k, k_be);
+  glv_half h1, h2;
+  glv_split(k, &h1, &h2);
+  if (h1.m[4] || h2.m[4]) return BN256_EINVAL;  // cannot happen: magnitudes are below 2^129
+  hostg1::be_store(k1_be, h1.m);
+  hostg1::be_store(k2_be, h2.m);
+  *k1_neg = h1.neg;
+  *k2_neg = h2.neg;
+  return BN256_OK;
+}
+
+// xs[i] = s_lo * lo[i*stride] + s_hi * hi[i*stride] (XYZZ, in the context's scratch): up to 2^13
+// outputs as two GLV half-chains of one quad per output plus k_glv_combine, up to fold_quad_max()
+// one quad per output over the full joint sparse form, above that one lane per output.
+static int fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32 stride, const uint8_t s_lo_be[32],
+                       const uint8_t s_hi_be[32], u32 n_lo, u32 n_hi, xyzz_mem** xs_out) {
+  const size_t n = std::max(n_lo, n_hi);
+  // two chains of n quads each: one wave per SIMD up to 2^13 outputs (measured: 2^13 0.96 -> 0.67 ms,
+  // 2^14 0.98 -> 1.08 ms)
+  const bool glv = n <= ((size_t)1 << 13), quad = n <= fold_quad_max();
+  xyzz_mem* xs = nullptr;
+  int rc = xyzz_scratch(ctx, glv ? 2 * n : n, &xs);
+  if (rc) return rc;
+  if (glv) {
+    jsf_arg jsf[2];
+    jsf_build_glv(s_lo_be, s_hi_be, jsf);
+    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, lo, hi, stride, jsf[0],
+                       jsf[1], xs, n_lo, n_hi);
+    hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
+  } else {
+    jsf_arg jsf;
+    jsf_build(s_lo_be, s_hi_be, &jsf);
+    if (quad)  // one full-length chain (grid.y = 1: the second argument is never read)
+      hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256), 1), dim3(256), 0, ctx->stream, lo, hi, stride, jsf,
+                         jsf, xs, n_lo, n_hi);
+    else
+      hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf, xs, n_lo,
+                         n_hi);
+  }
+  *xs_out = xs;
+  return BN256_OK;
 }
 
 extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
@@ -905,13 +1038,15 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
   xyzz_mem* xs = nullptr;
-  if (n && (rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
+  if (n && !broadcast && (rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
   if (n && broadcast) {
     // one scalar for every point (vectorPointMulOnScalar): the uniform NAF chain of the fold kernel
     static const uint8_t zero[32] = {0};
-    jsf_arg jsf;
-    jsf_build(scalars_be, zero, &jsf);
-    launch_fold_points(ctx, (const aff_mem*)(in->d + off), (const aff_mem*)(in->d + off), 1u, jsf, xs, (u32)n, 0u);
+    if ((rc = fold_points(ctx, (const aff_mem*)(in->d + off), (const aff_mem*)(in->d + off), 1u, scalars_be, zero, (u32)n,
+                          0u, &xs))) {
+      bn256_bases_free(ctx, r);
+      return rc;
+    }
     normalize_into(ctx, xs, r->d, n);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
@@ -1014,11 +1149,11 @@ extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off,
   if (!r) return rc;
   if (n) {
     xyzz_mem* xs;
-    if ((rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
-    jsf_arg jsf;
-    jsf_build(s_lo_be, s_hi_be, &jsf);
-    launch_fold_points(ctx, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, jsf, xs,
-                       (u32)n_lo, (u32)n_hi);
+    if ((rc = fold_points(ctx, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, s_lo_be,
+                          s_hi_be, (u32)n_lo, (u32)n_hi, &xs))) {
+      bn256_bases_free(ctx, r);
+      return rc;
+    }
     normalize_into(ctx, xs, r->d, n);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }

@@ -43,6 +43,10 @@ struct fe {
   { 0x10168311, 0x1aecdef8, 0x02a3f324, 0x1d12df6f, 0x0fc71ed9, 0x057924b5, 0x05a43451, 0x0c8c32d7, 0x0000b294 }
 #define FE_R2_LIMBS \
   { 0x1d8d65ed, 0x157f5abf, 0x058bb993, 0x0a97ab55, 0x043b578d, 0x0a4d6606, 0x085e0882, 0x1df0d5b9, 0x000ec411 }
+// beta: the cube root of unity in Fp with (beta x, y) = lambda (x, y) on G1 (GLV endomorphism; lambda in
+// bn256msm.hip), Montgomery form
+#define FE_BETA_LIMBS \
+  { 0x14d7f6f4, 0x084a8b7d, 0x1ea4e338, 0x10ea9d96, 0x06ff6659, 0x1f509ce9, 0x127412d9, 0x1736b20a, 0x000755ae }
 #define FE_B3_LIMBS \
   { 0x10438933, 0x10c69ce9, 0x07ebd96e, 0x17389e4d, 0x0f555c8d, 0x106b6e20, 0x10ec9cf3, 0x05a49885, 0x000217bd }
 

@@ -1028,13 +1028,21 @@ struct jsf_arg {
 // quad-cooperative doubling (3 multiply stages) and, for a non-zero pair, one quad-cooperative
 // addition of +-P, +-Q, +-(P+Q) or +-(P-Q) (4 stages).  out has max(n_lo, n_hi) entries; a
 // missing side counts as infinity (vectorPointsAdd padding, go/bppp/util.go:279-293).
+//
+// GLV: the call is one latency chain, so the scalars arrive split by the endomorphism,
+// s = s' + s'' lambda with |s'|, |s''| < 2^129 (glv_split in bn256msm.hip): blockIdx.y = 0 runs the
+// chain of (s_lo', s_hi') into out[i], blockIdx.y = 1 the chain of (s_lo'', s_hi'') into
+// out[n + i] -- the same P, Q tables, half the digits, side by side on otherwise idle SIMDs -- and
+// k_glv_combine adds out[i] + phi(out[n + i]).
 __global__ void __launch_bounds__(256) k_fold_points_quad(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
-                                                          u32 stride, jsf_arg jsf, xyzz_mem* __restrict__ out, u32 n_lo,
-                                                          u32 n_hi) {
+                                                          u32 stride, jsf_arg jsf0, jsf_arg jsf1,
+                                                          xyzz_mem* __restrict__ out, u32 n_lo, u32 n_hi) {
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   u32 i = gid >> 2, role = gid & 3u;
   u32 n = n_lo > n_hi ? n_lo : n_hi;
   if (i >= n) return;  // a quad leaves together
+  const jsf_arg& jsf = blockIdx.y ? jsf1 : jsf0;
+  out += (size_t)blockIdx.y * n;
   fe x, y;
   xyzz P, Q, S, D, acc;
   xyzz_set_inf(P);
@@ -1075,6 +1083,21 @@ __global__ void __launch_bounds__(256) k_fold_points_quad(const aff_mem* __restr
     acc = t;
   }
   if (role == 0) xyzz_store(&out[i], acc);
+}
+
+// out[i] += phi(out[n + i]), phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ): joins the two GLV chains of
+// k_fold_points_quad.  One quad per output.
+__global__ void __launch_bounds__(256) k_glv_combine(xyzz_mem* __restrict__ out, u32 n) {
+  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = gid >> 2, role = gid & 3u;
+  if (i >= n) return;
+  xyzz a, b, r;
+  xyzz_load(a, &out[i]);
+  xyzz_load(b, &out[(size_t)n + i]);
+  const fe beta = {FE_BETA_LIMBS};
+  b.x = fe_mul(b.x, beta);  // infinity (all-zero limbs) stays infinity
+  xyzz_add_quad(r, a, b, role);
+  if (role == 0) xyzz_store(&out[i], r);
 }
 
 // The same fold for many outputs (the first rounds of a 2^20-point WNLA / inner-product argument):

@@ -185,6 +185,12 @@ int bn256_last_timing(bn256_ctx* ctx, float* ms, int cap);
  * restatement and algebraic identities).  Returns 0 when every lane agrees. */
 int bn256_selftest(bn256_ctx* ctx);
 
+/* Host-side GLV split used by the generator folds (no counterpart in the reference: cloudflare's
+ * curvePoint.Mul does its own lattice decomposition internally): k mod n = k1 + k2 * lambda (mod n)
+ * with |k1|, |k2| < 2^129, lambda the eigenvalue of (x, y) -> (beta x, y).  Magnitudes as 32-byte
+ * big-endian, signs as 0 / 1.  Pure host arithmetic (no GPU needed); exported for the tests. */
+int bn256_glv_split(const uint8_t k_be[32], uint8_t k1_be[32], int* k1_neg, uint8_t k2_be[32], int* k2_neg);
+
 const char* bn256_strerror(int code);
 
 #ifdef __cplusplus

@@ -69,6 +69,32 @@ def test_host_g1_sum_matches_oracle():
     assert lib.bn256_g1_sum(ref.P.to_bytes(32, "big") + bytes(32), 1, out) == -3
 
 
+def test_glv_split_host_arithmetic():
+    """bn256_glv_split (pure host code behind the generator folds): k = k1 + k2*lambda mod n with
+    |k1|, |k2| < 2^129, and lambda*(x, y) = (beta*x, y) on the oracle's curve."""
+    import ctypes as C
+    import random
+    from crypto_amd import _lib
+    lib = _lib.load()
+    lam = 0x196ac037f07e9f9eecf9176e4f8bfcd513be518b5264ac23d
+    beta = 0xcb5601bf83f4fcf8877db38fb92fa161b9ff3815a6c2a92e
+    assert (lam * lam + lam + 1) % ref.N == 0 and pow(beta, 3, ref.P) == 1 and beta != 1
+    q = ref.mul(0xC0FFEE, ref.G0)
+    assert ref.mul(lam, q) == (beta * q[0] % ref.P, q[1])
+    rng = random.Random(7)
+    ks = [0, 1, 2, lam, lam - 1, ref.N - 1, ref.N, ref.N + 5, 2**256 - 1, 2**255, 2**128, 2**129 - 1]
+    ks += [rng.randrange(2**256) for _ in range(2000)] + [rng.randrange(2**k) for k in range(1, 256, 3)]
+    k1b, k2b = C.create_string_buffer(32), C.create_string_buffer(32)
+    n1, n2 = C.c_int(), C.c_int()
+    for k in ks:
+        assert lib.bn256_glv_split(k.to_bytes(32, "big"), k1b, C.byref(n1), k2b, C.byref(n2)) == 0
+        k1 = int.from_bytes(k1b.raw, "big") * (-1 if n1.value else 1)
+        k2 = int.from_bytes(k2b.raw, "big") * (-1 if n2.value else 1)
+        assert abs(k1) < 2**129 and abs(k2) < 2**129, hex(k)
+        assert (k1 + k2 * lam - k) % ref.N == 0, hex(k)
+    assert lib.bn256_glv_split(None, k1b, C.byref(n1), k2b, C.byref(n2)) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from crypto_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
