@@ -1254,6 +1254,12 @@ __global__ void __launch_bounds__(256) k_selftest(u32* __restrict__ errs, u32 n)
   // asm multiplier == portable multiplier (compare canonical forms)
   fe m1 = fe_canon(fe_mul(a, b)), m2 = fe_canon(fe_mul_portable(a, b));
   for (int j = 0; j < 9; j++) bad |= (m1.v[j] != m2.v[j]) ? 2u : 0u;
+  // a*b + c*d under one reduction == the two products added (signed un-normalised operands)
+  {
+    fe d1 = fe_sub(b, c), d2 = fe_sub(c, a);
+    fe f1 = fe_canon(fe_mul2add(d1, d2, fe_neg(a), b)), f2 = fe_canon(fe_sub(fe_mul(d1, d2), fe_mul(a, b)));
+    for (int j = 0; j < 9; j++) bad |= (f1.v[j] != f2.v[j]) ? 128u : 0u;
+  }
   // associativity and distributivity
   fe l = fe_canon(fe_mul(fe_mul(a, b), c)), r = fe_canon(fe_mul(a, fe_mul(b, c)));
   for (int j = 0; j < 9; j++) bad |= (l.v[j] != r.v[j]) ? 4u : 0u;
