@@ -249,15 +249,33 @@ hostg1::Pt pt_load(const Point& p) {
   if (hostg1::unmarshal(r, p.b)) throw std::runtime_error("bn256: malformed point");
   return r;
 }
-// new(bn256.G1).ScalarMult(p, k) for single points: host double-and-add (com() stays on the CPU,
-// SURVEY.md 8a row a5)
+// new(bn256.G1).ScalarMult(p, k) for single points on the host (com() stays on the CPU, SURVEY.md 8a
+// row a5).  k = k1 + k2*lambda (bn256_glv_split), lambda*(x, y) = (beta*x, y): one joint
+// double-and-add over +-P, +-phi(P) and their sum, 129 doublings instead of 256.
 Point scalarMult(const Point& p, const Fr& k) {
-  uint64_t w[4];
-  fr_to_raw(w, k);
-  hostg1::Pt base = pt_load(p), acc = hostg1::infinity();
-  for (int i = 255; i >= 0; i--) {
+  static const hostg1::Fp beta = [] {
+    const uint64_t w[4] = {0xb9ff3815a6c2a92eULL, 0x877db38fb92fa161ULL, 0xcb5601bf83f4fcf8ULL, 0};
+    return hostg1::from_raw(w);
+  }();
+  uint8_t kb[32], k1b[32], k2b[32];
+  int n1 = 0, n2 = 0;
+  fr_to_be(kb, k);
+  if (int rc = bn256_glv_split(kb, k1b, &n1, k2b, &n2)) throw std::runtime_error(bn256_strerror(rc));
+  uint64_t w1[4], w2[4];
+  hostg1::be_load(w1, k1b);
+  hostg1::be_load(w2, k2b);
+  hostg1::Pt A = pt_load(p), acc = hostg1::infinity();
+  if (hostg1::is_inf(A)) return p;
+  hostg1::Pt B = A;
+  B.x = hostg1::mul(A.x, beta);
+  const hostg1::Fp zero = {{0, 0, 0, 0}};
+  if (n1) A.y = hostg1::sub(zero, A.y);
+  if (n2) B.y = hostg1::sub(zero, B.y);
+  const hostg1::Pt AB = hostg1::padd(A, B);
+  for (int i = 129; i >= 0; i--) {
     acc = hostg1::dbl(acc);
-    if ((w[i >> 6] >> (i & 63)) & 1) acc = hostg1::padd(acc, base);
+    const unsigned b1 = (w1[i >> 6] >> (i & 63)) & 1, b2 = (w2[i >> 6] >> (i & 63)) & 1;
+    if (b1 | b2) acc = hostg1::padd(acc, (b1 & b2) ? AB : (b1 ? A : B));
   }
   return pt_from(acc);
 }
