@@ -7,7 +7,7 @@ import os
 from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbpamd.so")
+LIB_PATH = os.environ.get("BPAMD_LIB") or os.path.join(_HERE, "libbpamd.so")  # override: A/B builds
 EXPORTS = ["bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
            "bp_wnla_det", "bp_wnla_synthetic", "bp_ac_det"]
 _bp = None

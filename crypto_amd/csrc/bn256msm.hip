@@ -1411,11 +1411,11 @@ extern "C" int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, si
   return BN256_OK;
 }
 
-extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
-                                  const size_t* stride, const size_t* n, const bn256_frvec* const* v,
-                                  const size_t* v_off, const size_t* v_stride, const uint8_t* const* scale_be,
-                                  uint8_t out_xy_be[64]) {
-  if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
+// gathers the segments into the context's workspaces and enqueues one table-less MSM over them
+static int fr_multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* stride,
+                            const size_t* n, const bn256_frvec* const* v, const size_t* v_off, const size_t* v_stride,
+                            const uint8_t* const* scale_be, bool hold_stream, msm_pending* pend) {
+  pend->empty = true;
   size_t total = 0;
   int rc;
   for (int i = 0; i < k; i++) {
@@ -1423,7 +1423,6 @@ extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* cons
     if ((rc = range_check(b[i], off[i], n[i], stride[i])) || (rc = fr_range_check(v[i], v_off[i], n[i], v_stride[i]))) return rc;
     total += n[i];
   }
-  memset(out_xy_be, 0, 64);
   if (total == 0) return BN256_OK;
   if (total >= (1ull << 31)) return BN256_ETOOLARGE;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1443,15 +1442,53 @@ extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* cons
                        sc + pos * 32, (u32)n[i]);
     pos += n[i];
   }
-  bn256_bases tmp;
+  bn256_bases tmp;  // read only while enqueueing
   tmp.d = pts;
   tmp.n = total;
   tmp.levels = 1;
   tmp.c = 0;
-  hostg1::Pt r;
-  rc = msm_core(ctx, &tmp, 0, 1, total, sc, &r);
+  return msm_enqueue(ctx, &tmp, 0, 1, total, sc, 1, hold_stream, pend);
+}
+
+extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                                  const size_t* stride, const size_t* n, const bn256_frvec* const* v,
+                                  const size_t* v_off, const size_t* v_stride, const uint8_t* const* scale_be,
+                                  uint8_t out_xy_be[64]) {
+  if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
+  memset(out_xy_be, 0, 64);
+  msm_pending pend;
+  int rc = fr_multi_enqueue(ctx, k, b, off, stride, n, v, v_off, v_stride, scale_be, false, &pend);
   if (rc) return rc;
+  hostg1::Pt r;
+  if ((rc = msm_finish(ctx, &pend, &r))) return rc;
   hostg1::marshal(out_xy_be, r);
+  return BN256_OK;
+}
+
+extern "C" int bn256_msm_fr_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                                         const size_t* stride, const size_t* n, const bn256_frvec* const* v,
+                                         const size_t* v_off, const size_t* v_stride, const uint8_t* const* scale_be,
+                                         int* ticket) {
+  if (!ctx || k < 0 || !ticket || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
+  *ticket = -1;
+  HIPCHK(hipSetDevice(ctx->device));
+  int l = 0, rc;
+  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
+  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
+  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
+  bn256_ctx* lane = ctx->lane[l];
+  lane->tune_c = ctx->tune_c;
+  lane->tune_k = ctx->tune_k;
+  msm_pending* pend = new (std::nothrow) msm_pending();
+  if (!pend) return BN256_ENOMEM;
+  rc = fr_multi_enqueue(lane, k, b, off, stride, n, v, v_off, v_stride, scale_be, true, pend);
+  if (rc) {
+    (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
+    delete pend;
+    return rc;
+  }
+  ctx->pending[l] = pend;
+  *ticket = l;
   return BN256_OK;
 }
 

@@ -810,32 +810,50 @@ struct FSeg {
   View va;
   const Fr* scale;
 };
-Point devMsmFused(bn256_ctx* ctx, const std::vector<FSeg>& segs) {
+struct FusedArgs {
   std::vector<const bn256_bases*> hs;
   std::vector<const bn256_frvec*> vs;
   std::vector<size_t> off, stride, ns, voff, vstride;
   std::vector<std::vector<uint8_t>> scal;
   std::vector<const uint8_t*> sptr;
-  for (const FSeg& s : segs) {
-    size_t n = std::min(s.vg.len, s.va.len);
-    if (n == 0) continue;
-    hs.push_back(s.g->h);
-    vs.push_back(s.a->h);
-    off.push_back(s.vg.off);
-    stride.push_back(s.vg.stride);
-    ns.push_back(n);
-    voff.push_back(s.va.off);
-    vstride.push_back(s.va.stride);
-    scal.emplace_back();
-    if (s.scale) {
-      scal.back().resize(32);
-      fr_to_be(scal.back().data(), *s.scale);
+  explicit FusedArgs(const std::vector<FSeg>& segs) {
+    for (const FSeg& s : segs) {
+      size_t n = std::min(s.vg.len, s.va.len);
+      if (n == 0) continue;
+      hs.push_back(s.g->h);
+      vs.push_back(s.a->h);
+      off.push_back(s.vg.off);
+      stride.push_back(s.vg.stride);
+      ns.push_back(n);
+      voff.push_back(s.va.off);
+      vstride.push_back(s.va.stride);
+      scal.emplace_back();
+      if (s.scale) {
+        scal.back().resize(32);
+        fr_to_be(scal.back().data(), *s.scale);
+      }
     }
+    for (auto& v : scal) sptr.push_back(v.empty() ? nullptr : v.data());
   }
-  for (auto& v : scal) sptr.push_back(v.empty() ? nullptr : v.data());
+};
+Point devMsmFused(bn256_ctx* ctx, const std::vector<FSeg>& segs) {
+  FusedArgs a(segs);
   Point out;
-  chk(bn256_msm_fr_multi(ctx, (int)hs.size(), hs.data(), off.data(), stride.data(), ns.data(), vs.data(), voff.data(),
-                         vstride.data(), sptr.data(), out.b));
+  chk(bn256_msm_fr_multi(ctx, (int)a.hs.size(), a.hs.data(), a.off.data(), a.stride.data(), a.ns.data(), a.vs.data(),
+                         a.voff.data(), a.vstride.data(), a.sptr.data(), out.b));
+  return out;
+}
+// the same, enqueued on one of the library's lanes; devMsmWait returns the point
+int devMsmFusedSubmit(bn256_ctx* ctx, const std::vector<FSeg>& segs) {
+  FusedArgs a(segs);
+  int ticket = -1;
+  chk(bn256_msm_fr_multi_submit(ctx, (int)a.hs.size(), a.hs.data(), a.off.data(), a.stride.data(), a.ns.data(),
+                                a.vs.data(), a.voff.data(), a.vstride.data(), a.sptr.data(), &ticket));
+  return ticket;
+}
+Point devMsmWait(bn256_ctx* ctx, int ticket) {
+  Point out;
+  chk(bn256_msm_wait(ctx, ticket, out.b));
   return out;
 }
 
@@ -881,13 +899,18 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     View c0 = evens(c.n), c1 = odds(c.n), l0 = evens(l.n), l1 = odds(l.n), n0 = evens(n.n), n1 = odds(n.n);
     View G0 = evens(G.n), G1 = odds(G.n), H0 = evens(H.n), H1 = odds(H.n);
     Fr mu2 = mul(mu, mu);
+    // the two commitments' MSMs go to two lanes of the library; the round's inner products run on
+    // the context's own stream meanwhile (none of the three needs another's result)
+    int tx = devMsmFusedSubmit(ctx, {{&H, H0, &l, l1, nullptr}, {&H, H1, &l, l0, nullptr}, {&G, G0, &n, n1, &ro},
+                                     {&G, G1, &n, n0, &roinv}});
+    int tr = devMsmFusedSubmit(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
+    lap(PF_MSM);
     Fr vx = add(mul(devDot(ctx, n, n0, n, n1, &mu2), mul(fr_from_u64(2), roinv)),
                 add(devDot(ctx, c, c0, l, l1, nullptr), devDot(ctx, c, c1, l, l0, nullptr)));
     Fr vr = add(devDot(ctx, n, n1, n, n1, &mu2), devDot(ctx, c, c1, l, l1, nullptr));
     lap(PF_DOT);
-    Point mx = devMsmFused(ctx, {{&H, H0, &l, l1, nullptr}, {&H, H1, &l, l0, nullptr}, {&G, G0, &n, n1, &ro},
-                                 {&G, G1, &n, n0, &roinv}});
-    Point mr = devMsmFused(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
+    Point mx = devMsmWait(ctx, tx);
+    Point mr = devMsmWait(ctx, tr);
     lap(PF_MSM);
     Point X = pointAdd(scalarMult(g, vx), mx);
     Point R = pointAdd(scalarMult(g, vr), mr);

@@ -254,22 +254,27 @@ class Engine:
         self._chk(self.lib.bn256_msm_fr(self.ctx, bases.h, off, stride, n, v.h, v_off, v_stride, out))
         return out.raw
 
+    @staticmethod
+    def _fr_segments(segments: Sequence[tuple]):
+        m = max(len(segments), 1)
+        return ((C.c_void_p * m)(*[s[0].h for s in segments]), (C.c_size_t * m)(*[s[1] for s in segments]),
+                (C.c_size_t * m)(*[s[2] for s in segments]), (C.c_size_t * m)(*[s[3] for s in segments]),
+                (C.c_void_p * m)(*[s[4].h for s in segments]), (C.c_size_t * m)(*[s[5] for s in segments]),
+                (C.c_size_t * m)(*[s[6] for s in segments]),
+                (C.c_char_p * m)(*[(int(s[7]).to_bytes(32, "big") if len(s) > 7 and s[7] is not None else None)
+                                   for s in segments]))
+
     def msm_fr_multi(self, segments: Sequence[tuple]) -> bytes:
         """segments: (bases, off, stride, n, frvec, v_off, v_stride[, scale]) summed as one device MSM."""
-        k = len(segments)
-        m = max(k, 1)
-        hs = (C.c_void_p * m)(*[s[0].h for s in segments])
-        offs = (C.c_size_t * m)(*[s[1] for s in segments])
-        strides = (C.c_size_t * m)(*[s[2] for s in segments])
-        ns = (C.c_size_t * m)(*[s[3] for s in segments])
-        vs = (C.c_void_p * m)(*[s[4].h for s in segments])
-        voffs = (C.c_size_t * m)(*[s[5] for s in segments])
-        vstrides = (C.c_size_t * m)(*[s[6] for s in segments])
-        scales = (C.c_char_p * m)(*[(int(s[7]).to_bytes(32, "big") if len(s) > 7 and s[7] is not None else None)
-                                    for s in segments])
         out = C.create_string_buffer(64)
-        self._chk(self.lib.bn256_msm_fr_multi(self.ctx, k, hs, offs, strides, ns, vs, voffs, vstrides, scales, out))
+        self._chk(self.lib.bn256_msm_fr_multi(self.ctx, len(segments), *self._fr_segments(segments), out))
         return out.raw
+
+    def msm_fr_multi_submit(self, segments: Sequence[tuple]) -> int:
+        """The same, enqueued on a free lane; msm_wait(ticket) returns the point."""
+        t = C.c_int(-1)
+        self._chk(self.lib.bn256_msm_fr_multi_submit(self.ctx, len(segments), *self._fr_segments(segments), C.byref(t)))
+        return t.value
 
     def com_batch(self, g: bytes, h: bytes, a: Sequence[int], b: Sequence[int]) -> Bases:
         """[a_i*g + b_i*h]: com() of go/bp/util.go:92-94 over independent pairs (go/ve-ca/main.go:37-40)."""

@@ -169,6 +169,16 @@ int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const
                        const size_t* n, const bn256_frvec* const* v, const size_t* v_off, const size_t* v_stride,
                        const uint8_t* const* scale_be, uint8_t out_xy_be[64]);
 
+/* bn256_msm_fr_multi split in two, as bn256_msm_submit / bn256_msm_wait split bn256_msm_dev (same
+ * lanes, same tickets, same BN256_EBUSY rule; finish with bn256_msm_wait): the WNLA round's X and R
+ * commitments (go/bppp/docs_test.go:1312-1320) need neither each other's result nor the round's
+ * inner products, so the prover mirror enqueues both, computes v_x and v_r on the context's own
+ * stream meanwhile, and then waits.  The reference runs them one after the other on its single
+ * goroutine.  Every handle named here must stay alive and unchanged until the matching wait. */
+int bn256_msm_fr_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                              const size_t* stride, const size_t* n, const bn256_frvec* const* v, const size_t* v_off,
+                              const size_t* v_stride, const uint8_t* const* scale_be, int* ticket);
+
 /* Host-side sum of k marshalled points (combination of per-GPU partial MSMs). */
 int bn256_g1_sum(const uint8_t* xy_be, size_t k, uint8_t out_xy_be[64]);
 

@@ -183,3 +183,18 @@ def test_fused_multi_segment_msm(eng, orc):
     assert got == exp
     assert eng.msm_fr_multi([]) == bytes(64)
     assert eng.msm_fr_multi([(H, 0, 1, 0, l, 0, 1)]) == bytes(64)
+    # the submit / wait form: X and R of a round in flight together, a blocking call in between
+    rsegs = [(H, 1, 2, h1, l, 1, 2), (G, 1, 2, g1, n, 1, 2)]
+    want_r = eng.msm_fr_multi(rsegs)
+    tx, tr, te = eng.msm_fr_multi_submit(segs), eng.msm_fr_multi_submit(rsegs), eng.msm_fr_multi_submit([])
+    assert len({tx, tr, te}) == 3
+    with pytest.raises(Exception):
+        eng.msm_fr_multi_submit(rsegs)  # BN256_EBUSY: every lane holds a call
+    assert eng.fr_dot(l, 0, 1, nh, l, 0, 1, nh) == sum(x * x for x in lv) % N
+    assert eng.msm_wait(tr) == want_r and eng.msm_wait(tx) == exp and eng.msm_wait(te) == bytes(64)
+    # larger, table-less two-pass sizes through a lane
+    big = 1 << 15
+    Hb, lb = eng.random_bases(0xB1, big), eng.fr_random(0xB2, big)
+    seg = [(Hb, 0, 2, big // 2, lb, 1, 2), (Hb, 1, 2, big // 2, lb, 0, 2, ro)]
+    t1, t2 = eng.msm_fr_multi_submit(seg), eng.msm_fr_multi_submit(seg[:1])
+    assert eng.msm_wait(t1) == eng.msm_fr_multi(seg) and eng.msm_wait(t2) == eng.msm_fr_multi(seg[:1])

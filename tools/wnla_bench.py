@@ -12,6 +12,7 @@ from crypto_amd.bp import WNLA  # noqa: E402
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 eng = crypto_amd.Engine(0)
 w = WNLA(eng)
+w.synthetic(0xABCC, 1 << k, 1 << (k - 1))  # warm-up: lanes, workspaces, code objects (as tools/bp_bench.py)
 r = w.synthetic(0xABCD, 1 << k, 1 << (k - 1))
 r["config"] = f"WNLA |l| = 2^{k}, |n| = 2^{k-1}, synthetic generators"
 print(json.dumps(r))
