@@ -14,7 +14,7 @@ EXPORTS = [
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
-    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit",
+    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit",
 ]
 
 _lib = None

@@ -397,6 +397,8 @@ struct msm_pending {
   bool empty;   // n == 0: nothing was enqueued, the result is the identity
   int c;
   u32 q, nsets;
+  bool ready = false;  // bn256_msm_multi_submit on a shape that has no single pipeline: computed at submit
+  uint8_t ready_xy[64];
 };
 static void pending_free(msm_pending* p) { delete p; }
 
@@ -728,6 +730,11 @@ extern "C" int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64])
   bn256_ctx* lane = ctx->lane[ticket];
   msm_pending* pend = ctx->pending[ticket];
   ctx->pending[ticket] = nullptr;
+  if (pend->ready) {
+    memcpy(out_xy_be, pend->ready_xy, 64);
+    delete pend;
+    return BN256_OK;
+  }
   hostg1::Pt r;
   int rc = msm_finish(lane, pend, &r);
   delete pend;
@@ -759,50 +766,81 @@ extern "C" int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_
   return BN256_OK;
 }
 
+// bn256_msm_multi's segments as ONE pipeline on ctx's stream when that is possible (*single = true):
+// several small or table-less segments are gathered into one contiguous (points, scalars) pair (one
+// sort, one bucket reduction, one host tail); a single segment runs over its handle.  Segments
+// over large fixed-base tables keep their own pipelines (*single = false, nothing enqueued).
+static int multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* stride,
+                         const size_t* n, const uint8_t* const* scalars_be, bool hold_stream, msm_pending* pend,
+                         bool* single) {
+  pend->empty = true;
+  *single = true;
+  size_t total_n = 0;
+  bool big_table = false;
+  int rc;
+  for (int i = 0; i < k; i++) {
+    if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
+    if ((rc = range_check(b[i], off[i], n[i], stride ? stride[i] : 1))) return rc;
+    total_n += n[i];
+    if (b[i]->levels > 1 && n[i] >= (1u << 15)) big_table = true;
+  }
+  if (total_n == 0) return BN256_OK;
+  if (k == 1) {
+    if ((rc = ws_reserve(ctx, WS_SCALARS, n[0] * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be[0], n[0] * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (hold_stream) HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's buffer is not ours after return
+    return msm_enqueue(ctx, b[0], off[0], stride ? stride[0] : 1, n[0], (const uint8_t*)ctx->ws[WS_SCALARS], 1, hold_stream,
+                       pend);
+  }
+  if (big_table || total_n >= (1ull << 31)) {
+    *single = false;
+    return BN256_OK;
+  }
+  if ((rc = ws_reserve(ctx, WS_GATHER, total_n * sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, total_n * 32)))
+    return rc;
+  aff_mem* pts = (aff_mem*)ctx->ws[WS_GATHER];
+  uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
+  size_t pos = 0;
+  fr_arg none;
+  memset(&none, 0, sizeof none);
+  for (int i = 0; i < k; i++) {
+    if (!n[i]) continue;
+    HIPCHK(hipMemcpyAsync(sc + pos * 32, scalars_be[i], n[i] * 32, hipMemcpyHostToDevice, ctx->stream));
+    pos += n[i];
+  }
+  if (hold_stream) HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's buffers are not ours after return
+  pos = 0;
+  for (int i = 0; i < k; i++) {
+    if (!n[i]) continue;
+    hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(n[i], 256)), dim3(256), 0, ctx->stream,
+                       (const uint4*)(b[i]->d + off[i]), (u32)(stride ? stride[i] : 1), (uint4*)(pts + pos),
+                       (const uint8_t*)nullptr, 1u, none, 0u, (uint8_t*)nullptr, (u32)n[i]);
+    pos += n[i];
+  }
+  bn256_bases tmp;  // read only while enqueueing
+  tmp.d = pts;
+  tmp.n = total_n;
+  tmp.levels = 1;
+  tmp.c = 0;
+  return msm_enqueue(ctx, &tmp, 0, 1, total_n, sc, 1, hold_stream, pend);
+}
+
 extern "C" int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
                                        const size_t* stride, const size_t* n, const uint8_t* const* scalars_be,
                                        uint8_t out_xy_be[64]) {
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
   HIPCHK(hipSetDevice(ctx->device));
-  // Small or table-less segments are gathered into one contiguous (points, scalars) pair and run
-  // as ONE device MSM (one sort, one bucket reduction, one host tail); segments over large
-  // fixed-base tables keep their own pipeline so that the tables are used.
-  size_t total_n = 0;
-  bool big_table = false;
-  for (int i = 0; i < k; i++) {
-    if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
-    int rc = range_check(b[i], off[i], n[i], stride ? stride[i] : 1);
+  {
+    msm_pending pend;
+    bool single;
+    int rc = multi_enqueue(ctx, k, b, off, stride, n, scalars_be, false, &pend, &single);
     if (rc) return rc;
-    total_n += n[i];
-    if (b[i]->levels > 1 && n[i] >= (1u << 15)) big_table = true;
-  }
-  if (k > 1 && !big_table && total_n > 0 && total_n < (1ull << 31)) {
-    int rc;
-    if ((rc = ws_reserve(ctx, WS_GATHER, total_n * sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, total_n * 32)))
-      return rc;
-    aff_mem* pts = (aff_mem*)ctx->ws[WS_GATHER];
-    uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
-    size_t pos = 0;
-    fr_arg none;
-    memset(&none, 0, sizeof none);
-    for (int i = 0; i < k; i++) {
-      if (!n[i]) continue;
-      HIPCHK(hipMemcpyAsync(sc + pos * 32, scalars_be[i], n[i] * 32, hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(n[i], 256)), dim3(256), 0, ctx->stream,
-                         (const uint4*)(b[i]->d + off[i]), (u32)(stride ? stride[i] : 1), (uint4*)(pts + pos),
-                         (const uint8_t*)nullptr, 1u, none, 0u, (uint8_t*)nullptr, (u32)n[i]);
-      pos += n[i];
+    if (single) {
+      hostg1::Pt r;
+      if ((rc = msm_finish(ctx, &pend, &r))) return rc;
+      hostg1::marshal(out_xy_be, r);
+      return BN256_OK;
     }
-    bn256_bases tmp;
-    tmp.d = pts;
-    tmp.n = total_n;
-    tmp.levels = 1;
-    tmp.c = 0;
-    hostg1::Pt r;
-    rc = msm_core(ctx, &tmp, 0, 1, total_n, sc, &r);
-    if (rc) return rc;
-    hostg1::marshal(out_xy_be, r);
-    return BN256_OK;
   }
   hostg1::Pt total = hostg1::infinity();
   float ms[7] = {0};
@@ -821,6 +859,36 @@ extern "C" int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases*
 extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
                                const uint8_t* const* scalars_be, uint8_t out_xy_be[64]) {
   return bn256_msm_multi_strided(ctx, k, b, off, nullptr, n, scalars_be, out_xy_be);
+}
+
+extern "C" int bn256_msm_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
+                                      const size_t* n, const uint8_t* const* scalars_be, int* ticket) {
+  if (!ctx || k < 0 || !ticket || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
+  *ticket = -1;
+  HIPCHK(hipSetDevice(ctx->device));
+  int l = 0, rc;
+  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
+  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
+  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
+  bn256_ctx* lane = ctx->lane[l];
+  lane->tune_c = ctx->tune_c;
+  lane->tune_k = ctx->tune_k;
+  msm_pending* pend = new (std::nothrow) msm_pending();
+  if (!pend) return BN256_ENOMEM;
+  bool single = true;
+  rc = multi_enqueue(lane, k, b, off, nullptr, n, scalars_be, true, pend, &single);
+  if (!rc && !single) {  // several large fixed-base tables: no single pipeline to enqueue, done here
+    rc = bn256_msm_multi_strided(lane, k, b, off, nullptr, n, scalars_be, pend->ready_xy);
+    pend->ready = true;
+  }
+  if (rc) {
+    (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
+    delete pend;
+    return rc;
+  }
+  ctx->pending[l] = pend;
+  *ticket = l;
+  return BN256_OK;
 }
 
 // ---------------------------------------------------------------------------- element-wise

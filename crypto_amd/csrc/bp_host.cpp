@@ -375,21 +375,38 @@ struct Seg {
   FrVec a;
 };
 // sum of vectorPointScalarMul over segments (go/bp/util.go:165-175): one bn256_msm_multi
-Point msmSegments(bn256_ctx* ctx, const std::vector<Seg>& segs) {
+struct SegArgs {
   std::vector<const bn256_bases*> hs;
   std::vector<size_t> offs, ns;
   std::vector<std::vector<uint8_t>> raws;
   std::vector<const uint8_t*> ptrs;
-  for (const Seg& s : segs) {
-    if (s.off + s.a.size() > s.g->n) throw std::runtime_error("invalid length for scalar mul");
-    hs.push_back(s.g->h);
-    offs.push_back(s.off);
-    ns.push_back(s.a.size());
-    raws.push_back(scalarBytes(s.a));
+  explicit SegArgs(const std::vector<Seg>& segs) {
+    for (const Seg& s : segs) {
+      if (s.off + s.a.size() > s.g->n) throw std::runtime_error("invalid length for scalar mul");
+      hs.push_back(s.g->h);
+      offs.push_back(s.off);
+      ns.push_back(s.a.size());
+      raws.push_back(scalarBytes(s.a));
+    }
+    for (auto& r : raws) ptrs.push_back(r.data());
   }
-  for (auto& r : raws) ptrs.push_back(r.data());
+};
+Point msmSegments(bn256_ctx* ctx, const std::vector<Seg>& segs) {
+  SegArgs a(segs);
   Point out;
-  chk(bn256_msm_multi(ctx, (int)segs.size(), hs.data(), offs.data(), ns.data(), ptrs.data(), out.b));
+  chk(bn256_msm_multi(ctx, (int)segs.size(), a.hs.data(), a.offs.data(), a.ns.data(), a.ptrs.data(), out.b));
+  return out;
+}
+// the same on one of the library's lanes (independent commitments of one step); msmWait returns the point
+int msmSegmentsSubmit(bn256_ctx* ctx, const std::vector<Seg>& segs) {
+  SegArgs a(segs);
+  int ticket = -1;
+  chk(bn256_msm_multi_submit(ctx, (int)segs.size(), a.hs.data(), a.offs.data(), a.ns.data(), a.ptrs.data(), &ticket));
+  return ticket;
+}
+Point msmWait(bn256_ctx* ctx, int ticket) {
+  Point out;
+  chk(bn256_msm_wait(ctx, ticket, out.b));
   return out;
 }
 // vectorPointScalarMul, go/bp/util.go:165-175
@@ -418,10 +435,15 @@ InnerProductProof innerArgProof(bn256_ctx* ctx, int N, DevPoints G, DevPoints H,
     FrVec alo = slice(a, 0, n1), ahi = slice(a, n1, N), blo = slice(b, 0, n1), bhi = slice(b, n1, N);
     Fr cl = vectorMul(alo, bhi), cr = vectorMul(ahi, blo);
     // L = vecCom(G[n1:], H[:n1], a[:n1], b[n1:]) + cl*U ;  R = vecCom(G[:n1], H[n1:], a[n1:], b[:n1]) + cr*U
-    Point L = pointAdd(msmSegments(ctx, {{&G, n1, alo}, {&H, 0, bhi}}), scalarMult(U, cl));
-    Point R = pointAdd(msmSegments(ctx, {{&G, 0, ahi}, {&H, n1, blo}}), scalarMult(U, cr));
     // P = productCom(G, H, U, a, b), go/bp/util.go:100-104 (recomputed at every level, main.go:347)
-    Point P = pointAdd(msmSegments(ctx, {{&G, 0, a}, {&H, 0, b}}), scalarMult(U, vectorMul(a, b)));
+    // The three MSMs are independent: one lane each, the host's c*U terms under them.
+    int tl = msmSegmentsSubmit(ctx, {{&G, n1, alo}, {&H, 0, bhi}});
+    int tr = msmSegmentsSubmit(ctx, {{&G, 0, ahi}, {&H, n1, blo}});
+    int tp = msmSegmentsSubmit(ctx, {{&G, 0, a}, {&H, 0, b}});
+    Point ul = scalarMult(U, cl), ur = scalarMult(U, cr), up = scalarMult(U, vectorMul(a, b));
+    Point L = pointAdd(msmWait(ctx, tl), ul);
+    Point R = pointAdd(msmWait(ctx, tr), ur);
+    Point P = pointAdd(msmWait(ctx, tp), up);
     proof.L.push_back(L);
     proof.R.push_back(R);
     Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, L, R});
@@ -543,11 +565,14 @@ BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const
   FrVec al = toBits(v, N);
   FrVec ar = vectorSub(al, onen);
   Fr alpha = rd.values(1)[0];
-  Point A = pointAdd(msmSegments(ctx, {{&p.G, 0, al}, {&p.H, 0, ar}}), scalarMult(p.h, alpha));
+  int ta = msmSegmentsSubmit(ctx, {{&p.G, 0, al}, {&p.H, 0, ar}});  // A and S: independent, a lane each
   FrVec sl = rd.values(N), sr = rd.values(N);
   Fr ro = rd.values(1)[0];
-  Point S = pointAdd(msmSegments(ctx, {{&p.G, 0, sl}, {&p.H, 0, sr}}), scalarMult(p.h, ro));
+  int ts = msmSegmentsSubmit(ctx, {{&p.G, 0, sl}, {&p.H, 0, sr}});
+  Point ha = scalarMult(p.h, alpha), hs = scalarMult(p.h, ro);
   Point V = com(p.g, p.h, v, prv);
+  Point A = pointAdd(msmWait(ctx, ta), ha);
+  Point S = pointAdd(msmWait(ctx, ts), hs);
   BulletProof proof;
   proof.V = V;
   proof.ACom = A;

@@ -169,6 +169,18 @@ class Engine:
         self._chk(self.lib.bn256_msm_multi_strided(self.ctx, k, hs, offs, strides, ns, ptrs, out))
         return out.raw
 
+    def msm_multi_submit(self, segments: Sequence[tuple]) -> int:
+        """segments: (bases, off, scalars), stride 1; enqueued on a free lane, msm_wait(ticket) returns the point."""
+        k = len(segments)
+        hs = (C.c_void_p * max(k, 1))(*[s[0].h for s in segments])
+        offs = (C.c_size_t * max(k, 1))(*[s[1] for s in segments])
+        raws = [scalars_to_bytes(s[2]) for s in segments]
+        ns = (C.c_size_t * max(k, 1))(*[len(r) // 32 for r in raws])
+        ptrs = (C.c_char_p * max(k, 1))(*raws)
+        t = C.c_int(-1)
+        self._chk(self.lib.bn256_msm_multi_submit(self.ctx, k, hs, offs, ns, ptrs, C.byref(t)))
+        return t.value
+
     # reference-named helpers (go/bp/util.go) -----------------------------------------
     def vector_point_scalar_mul(self, g: Bases, a: Sequence[int]) -> bytes:
         """vectorPointScalarMul, go/bp/util.go:165-175 (length mismatch panics there)."""

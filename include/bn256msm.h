@@ -83,6 +83,14 @@ int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]);
 int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
                     const uint8_t* const* scalars_be, uint8_t out_xy_be[64]);
 
+/* bn256_msm_multi split in two like bn256_msm_submit / bn256_msm_wait (same lanes and tickets,
+ * BN256_EBUSY when all are taken; finish with bn256_msm_wait): L, R and P of an inner-product level
+ * (go/bp/main.go:340-341,347) and A, S (go/bp/main.go:89,95) are independent commitments that the
+ * reference computes one after the other.  The host scalars are copied before the call returns; the
+ * bases handles must stay alive until the matching wait. */
+int bn256_msm_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off, const size_t* n,
+                           const uint8_t* const* scalars_be, int* ticket);
+
 /* As bn256_msm_multi with a point stride per segment: segment j sums scalars[j][i] *
  * bases[j][off[j] + i*stride[j]].  stride 2 addresses the even / odd halves that the WNLA round
  * takes with reducePoints (go/bppp/util.go:213-226, go/bppp/docs_test.go:1297-1320). */

@@ -4,6 +4,8 @@ import hashlib
 
 import pytest
 
+import crypto_amd
+
 import bn256_ref as ref
 from cases import CASES, N_ORDER
 from oracle_c import build_case
@@ -135,6 +137,33 @@ def test_msm_multi_matches_vec_com(eng, orc):
     got = eng.msm_multi([(G, n1, sc[:n1]), (H, 0, sc[n1:n])])
     want = orc.msm(graw[64 * n1:64 * n] + graw[64 * n:64 * (n + n1)], sraw[:32 * n])
     assert got == want
+
+
+def test_msm_multi_submit_matches_blocking(eng, orc):
+    """bn256_msm_multi_submit / bn256_msm_wait: L, R, P of an inner-product level (go/bp/main.go:340-347)
+    in flight together give the bytes of the blocking bn256_msm_multi; single segments and segments over
+    a fixed-base table go through the same tickets."""
+    n = 64
+    braw = orc.synth_bases(0x51, 2 * n)
+    sraw = orc.synth_scalars(0x52, 2 * n)
+    a = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(2 * n)]
+    G, H = eng.upload(braw[:64 * n]), eng.upload(braw[64 * n:])
+    h = n // 2
+    shapes = [[(G, h, a[:h]), (H, 0, a[n + h:])], [(G, 0, a[h:n]), (H, h, a[n:n + h])], [(G, 0, a[:n]), (H, 0, a[n:])]]
+    want = [eng.msm_multi(sg) for sg in shapes]
+    assert want[2] == orc.msm(braw, sraw)
+    tickets = [eng.msm_multi_submit(sg) for sg in shapes]
+    with pytest.raises(Exception):
+        eng.msm_multi_submit(shapes[0])  # BN256_EBUSY
+    assert [eng.msm_wait(t) for t in reversed(tickets)] == list(reversed(want))
+    # one segment; no segment; several segments over fixed-base tables of >= 2^15 points
+    t1, t0 = eng.msm_multi_submit([(G, 3, a[:17])]), eng.msm_multi_submit([])
+    assert eng.msm_wait(t1) == eng.msm_multi([(G, 3, a[:17])]) and eng.msm_wait(t0) == INF
+    m = 1 << 15
+    T1, T2 = eng.random_bases(0x53, m, flags=crypto_amd.PRECOMPUTE), eng.random_bases(0x54, m, flags=crypto_amd.PRECOMPUTE)
+    big = [int.from_bytes(hashlib.sha256(b"%d" % i).digest(), "big") % N_ORDER for i in range(m)]
+    tb = eng.msm_multi_submit([(T1, 0, big), (T2, 0, big[::-1])])
+    assert eng.msm_wait(tb) == eng.msm_multi([(T1, 0, big), (T2, 0, big[::-1])])
 
 
 def test_linearity_and_permutation_at_2_20(eng):
