@@ -14,7 +14,7 @@ EXPORTS = [
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
-    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit",
+    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait",
 ]
 
 _lib = None
@@ -77,6 +77,14 @@ def load() -> C.CDLL:
     lib.bn256_msm_fr_multi.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(vp),
                                        C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p), u8p]
     lib.bn256_com_batch.argtypes = [vp, u8p, u8p, u8p, u8p, sz, C.POINTER(vp)]
+    lib.bn256_msm_fr_multi_submit.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
+                                              C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p),
+                                              C.POINTER(C.c_int)]
+    lib.bn256_msm_multi_submit.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p),
+                                           C.POINTER(C.c_int)]
+    lib.bn256_fold2_submit.argtypes = [vp, vp, sz, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp), C.POINTER(C.c_int)]
+    lib.bn256_fold_wait.argtypes = [vp, i]
+    lib.bn256_glv_split.argtypes = [u8p, u8p, C.POINTER(C.c_int), u8p, C.POINTER(C.c_int)]
     lib.bn256_g1_sum.argtypes = [u8p, sz, u8p]
     lib.bn256_ctx_set_tuning.argtypes = [vp, i, i]
     lib.bn256_last_timing.argtypes = [vp, C.POINTER(C.c_float), i]

@@ -399,6 +399,7 @@ struct msm_pending {
   u32 q, nsets;
   bool ready = false;  // bn256_msm_multi_submit on a shape that has no single pipeline: computed at submit
   uint8_t ready_xy[64];
+  bool fold = false;   // a bn256_fold2_submit ticket: nothing to finish but the lane's stream
 };
 static void pending_free(msm_pending* p) { delete p; }
 
@@ -725,7 +726,8 @@ extern "C" int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off
 }
 
 extern "C" int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]) {
-  if (!ctx || !out_xy_be || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket]) return BN256_EINVAL;
+  if (!ctx || !out_xy_be || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket] || ctx->pending[ticket]->fold)
+    return BN256_EINVAL;
   HIPCHK(hipSetDevice(ctx->device));
   bn256_ctx* lane = ctx->lane[ticket];
   msm_pending* pend = ctx->pending[ticket];
@@ -1203,30 +1205,83 @@ extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const 
   return BN256_OK;
 }
 
-extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
-                           size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32],
-                           const uint8_t s_hi_be[32], bn256_bases** out) {
-  if (!ctx || !lo || !hi || !out || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
+// fold + normalisation on `on`'s stream and scratch; the caller synchronises
+static int fold2_enqueue(bn256_ctx* on, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                         size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                         bn256_bases** out) {
   *out = nullptr;
   int rc;
   if ((rc = range_check(lo, lo_off, n_lo, stride))) return rc;
   if ((rc = range_check(hi, hi_off, n_hi, stride))) return rc;
   size_t n = std::max(n_lo, n_hi);
-  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipSetDevice(on->device));
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
   if (n) {
     xyzz_mem* xs;
-    if ((rc = fold_points(ctx, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, s_lo_be,
+    if ((rc = fold_points(on, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, s_lo_be,
                           s_hi_be, (u32)n_lo, (u32)n_hi, &xs))) {
-      bn256_bases_free(ctx, r);
+      bn256_bases_free(on, r);
       return rc;
     }
-    normalize_into(ctx, xs, r->d, n);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+    normalize_into(on, xs, r->d, n);
   }
   *out = r;
+  return BN256_OK;
+}
+
+extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                           size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32],
+                           const uint8_t s_hi_be[32], bn256_bases** out) {
+  if (!ctx || !lo || !hi || !out || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
+  int rc = fold2_enqueue(ctx, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, out);
+  if (rc) return rc;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    bn256_bases_free(ctx, *out);
+    *out = nullptr;
+    return BN256_EHIP;
+  }
+  return BN256_OK;
+}
+
+extern "C" int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo,
+                                  const bn256_bases* hi, size_t hi_off, size_t n_hi, size_t stride,
+                                  const uint8_t s_lo_be[32], const uint8_t s_hi_be[32], bn256_bases** out, int* ticket) {
+  if (!ctx || !lo || !hi || !out || !ticket || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
+  *out = nullptr;
+  *ticket = -1;
+  HIPCHK(hipSetDevice(ctx->device));
+  int l = 0, rc;
+  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
+  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
+  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
+  msm_pending* pend = new (std::nothrow) msm_pending();
+  if (!pend) return BN256_ENOMEM;
+  pend->empty = true;
+  pend->fold = true;
+  if ((rc = fold2_enqueue(ctx->lane[l], lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, out))) {
+    (void)hipStreamSynchronize(ctx->lane[l]->stream);
+    delete pend;
+    return rc;
+  }
+  ctx->pending[l] = pend;
+  *ticket = l;
+  return BN256_OK;
+}
+
+extern "C" int bn256_fold_wait(bn256_ctx* ctx, int ticket) {
+  if (!ctx || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket] || !ctx->pending[ticket]->fold)
+    return BN256_EINVAL;
+  HIPCHK(hipSetDevice(ctx->device));
+  delete ctx->pending[ticket];
+  ctx->pending[ticket] = nullptr;
+  hipError_t e = hipStreamSynchronize(ctx->lane[ticket]->stream);
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    return BN256_EHIP;
+  }
   return BN256_OK;
 }
 

@@ -452,13 +452,17 @@ InnerProductProof innerArgProof(bn256_ctx* ctx, int N, DevPoints G, DevPoints H,
     uint8_t xb[32], xib[32];
     fr_to_be(xb, x);
     fr_to_be(xib, xinv);
+    // the two folds are independent latency chains: G's on a lane, H's on the context's stream, the
+    // host's a', b' under both
     bn256_bases *g1 = nullptr, *h1 = nullptr;
-    chk(bn256_fold(ctx, G.h, 0, G.h, n1, 1, n1, xib, xb, &g1));
+    int tg = -1;
+    chk(bn256_fold2_submit(ctx, G.h, 0, n1, G.h, n1, n1, 1, xib, xb, &g1, &tg));
     DevPoints G1(ctx, g1);
     chk(bn256_fold(ctx, H.h, 0, H.h, n1, 1, n1, xb, xib, &h1));
     DevPoints H1(ctx, h1);
     FrVec a1 = vectorAdd(vectorMulOnScalar(alo, x), vectorMulOnScalar(ahi, xinv));
     FrVec b1 = vectorAdd(vectorMulOnScalar(bhi, x), vectorMulOnScalar(blo, xinv));
+    chk(bn256_fold_wait(ctx, tg));
     G = std::move(G1);
     H = std::move(H1);
     a = a1;
@@ -484,11 +488,13 @@ std::string innerArgVerify(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, cons
     fr_to_be(xb, x);
     fr_to_be(xib, xinv);
     bn256_bases *g1 = nullptr, *h1 = nullptr;
-    chk(bn256_fold(ctx, G.h, 0, G.h, n1, 1, n1, xib, xb, &g1));
+    int tg = -1;
+    chk(bn256_fold2_submit(ctx, G.h, 0, n1, G.h, n1, n1, 1, xib, xb, &g1, &tg));  // as in innerArgProof
     DevPoints G1(ctx, g1);
     chk(bn256_fold(ctx, H.h, 0, H.h, n1, 1, n1, xb, xib, &h1));
     DevPoints H1(ctx, h1);
     P = pointAdd(pointAdd(scalarMult(proof.L[deep], x2), P), scalarMult(proof.R[deep], x2inv));
+    chk(bn256_fold_wait(ctx, tg));
     G = std::move(G1);
     H = std::move(H1);
     N = (int)n1;
@@ -947,11 +953,14 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     fr_to_be(oneb, kFrOne);
     fr_to_be(yb, y);
     fr_to_be(rob, ro);
+    // G's fold (a full-length chain: ro is a 256-bit scalar) goes to a lane; H's fold, the three
+    // scalar-vector folds and the host's C' run meanwhile
     bn256_bases *hn = nullptr, *gn = nullptr;
+    int tg = -1;
+    chk(bn256_fold2_submit(ctx, G.h, G0.off, G0.len, G.h, G1.off, G1.len, 2, rob, yb, &gn, &tg));
+    DevPoints Gn(ctx, gn);
     chk(bn256_fold2(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn));
     DevPoints Hn(ctx, hn);
-    chk(bn256_fold2(ctx, G.h, G0.off, G0.len, G.h, G1.off, G1.len, 2, rob, yb, &gn));
-    DevPoints Gn(ctx, gn);
     lap(PF_PTFOLD);
     DevFr c_ = devFoldHalves(ctx, c, kFrOne, y);
     DevFr l_ = devFoldHalves(ctx, l, kFrOne, y);
@@ -959,6 +968,9 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     lap(PF_FRFOLD);
     Point C_ = pointAdd(C, scalarMult(X, y));
     C_ = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
+    lap(PF_HOSTPT);
+    chk(bn256_fold_wait(ctx, tg));
+    lap(PF_PTFOLD);
     G = std::move(Gn);
     H = std::move(Hn);
     c = std::move(c_);

@@ -233,6 +233,18 @@ class Engine:
                                        int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"), C.byref(h)))
         return Bases(self, h)
 
+    def fold2_submit(self, lo: Bases, lo_off: int, n_lo: int, hi: Bases, hi_off: int, n_hi: int, s_lo: int, s_hi: int,
+                     stride: int = 1) -> tuple:
+        """fold2 on a free lane: (handle, ticket); the handle's contents are defined after fold_wait(ticket)."""
+        h, t = C.c_void_p(), C.c_int(-1)
+        self._chk(self.lib.bn256_fold2_submit(self.ctx, lo.h, lo_off, n_lo, hi.h, hi_off, n_hi, stride,
+                                              int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"),
+                                              C.byref(h), C.byref(t)))
+        return Bases(self, h), t.value
+
+    def fold_wait(self, ticket: int) -> None:
+        self._chk(self.lib.bn256_fold_wait(self.ctx, ticket))
+
     # Fr vectors on the device (go/bp/util.go:106-163, go/bppp/util.go:143-176,237-277) -----
     def fr_upload(self, scalars: Sequence[int] | bytes) -> FrVec:
         raw = scalars if isinstance(scalars, (bytes, bytearray)) else scalars_to_bytes(scalars)

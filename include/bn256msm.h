@@ -126,6 +126,18 @@ int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_l
                 size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
                 bn256_bases** out);
 
+/* bn256_fold2 split in two: the generator folds of one level, g' = x^-1 G_lo + x G_hi and
+ * h' = x H_lo + x^-1 H_hi (go/bp/main.go:355-356; go/bppp/docs_test.go:1325-1326), are independent
+ * latency chains that the reference runs one after the other.  submit enqueues fold and
+ * normalisation on a free lane (the lanes and tickets of bn256_msm_submit, BN256_EBUSY when all are
+ * taken) and returns the new handle at once; its contents are defined only after bn256_fold_wait
+ * on that ticket (bn256_msm_wait rejects a fold ticket and vice versa).  lo and hi must stay alive
+ * until then. */
+int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                       size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                       bn256_bases** out, int* ticket);
+int bn256_fold_wait(bn256_ctx* ctx, int ticket);
+
 /* Marshal() of n points of a handle into host memory. */
 int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be);
 

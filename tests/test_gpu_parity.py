@@ -238,6 +238,39 @@ def test_scalar_mul_batch_1024_vs_oracle(eng, orc):
     assert b"".join(eng.vector_point_mul_on_scalar(h, sc[0]).download()) == orc.scalar_mul_each(braw, sraw[:32], broadcast=True)
 
 
+def test_fold_submit_wait(eng, orc):
+    """bn256_fold2_submit / bn256_fold_wait: both generator folds of a level (go/bp/main.go:355-356) in
+    flight, a blocking fold and an MSM ticket beside them; ticket kinds do not mix."""
+    n = 96
+    g = eng.random_bases(0x61, 2 * n)
+    x = 0x1234567890abcdef << 150 | 0xfeed
+    xinv = pow(x, -1, N_ORDER)
+    want_g = eng.fold(g, 0, g, n, n, xinv, x).download()
+    want_h = eng.fold(g, 0, g, n, n, x, xinv).download()
+    want_r = eng.fold2(g, 0, 5, g, 7, 3, x, xinv, stride=2).download()
+    hg, tg = eng.fold2_submit(g, 0, n, g, n, n, xinv, x)
+    hh, th = eng.fold2_submit(g, 0, n, g, n, n, x, xinv)
+    hr, tr = eng.fold2_submit(g, 0, 5, g, 7, 3, x, xinv, stride=2)
+    assert len({tg, th, tr}) == 3
+    with pytest.raises(Exception):
+        eng.fold2_submit(g, 0, n, g, n, n, x, xinv)  # BN256_EBUSY
+    with pytest.raises(Exception):
+        eng.msm_wait(tg)  # a fold ticket
+    assert eng.fold(g, 0, g, n, n, 3, 5).download()[0] == orc.add(orc.mul(g.download(0, 1)[0], 3),
+                                                                   orc.mul(g.download(n, 1)[0], 5))
+    eng.fold_wait(th)
+    tm = eng.msm_multi_submit([(g, 0, [1, 2, 3])])
+    with pytest.raises(Exception):
+        eng.fold_wait(tm)  # an MSM ticket
+    eng.fold_wait(tr)
+    eng.fold_wait(tg)
+    assert eng.msm_wait(tm) == eng.msm_multi([(g, 0, [1, 2, 3])])
+    assert hg.download() == want_g and hh.download() == want_h and hr.download() == want_r
+    e, te = eng.fold2_submit(g, 0, 0, g, 0, 0, x, xinv)
+    eng.fold_wait(te)
+    assert len(e) == 0
+
+
 def test_fold_lane_per_output_kernel(eng, orc):
     """Generator folds of more than 28672 outputs run one lane per output (k_fold_points), up to 2^13
     outputs two GLV half-chains of one quad per output, in between one quad over the full chain: the
