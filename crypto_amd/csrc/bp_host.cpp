@@ -535,15 +535,23 @@ DevPoints points(bn256_ctx* ctx, ByteStream& rd, int n) {
   return DevPoints(ctx, out);
 }
 
-// NewBulletProofPublic, go/bp/main.go:27-34 (draw order: G[0..n), H[0..n), U, g, h)
+// NewBulletProofPublic, go/bp/main.go:27-34 (draw order: G[0..n), H[0..n), U, g, h).  The five
+// points() calls of the reference draw 2n + 3 scalars one after the other, so one batch of 2n + 3
+// base multiplications yields the same points: a single latency chain on the device instead of five.
 BulletProofPublic newBulletProofPublic(bn256_ctx* ctx, ByteStream& rd, int n) {
   BulletProofPublic p;
   p.N = n;
-  p.G = points(ctx, rd, n);
-  p.H = points(ctx, rd, n);
-  p.U = points(ctx, rd, 1).at(0);
-  p.g = points(ctx, rd, 1).at(0);
-  p.h = points(ctx, rd, 1).at(0);
+  DevPoints all = points(ctx, rd, 2 * n + 3);
+  std::vector<uint8_t> raw(64 * all.n);
+  chk(bn256_bases_download(ctx, all.h, 0, all.n, raw.data()));
+  bn256_bases *g = nullptr, *h = nullptr;
+  chk(bn256_bases_upload(ctx, raw.data(), (size_t)n, 0, &g));
+  p.G = DevPoints(ctx, g);
+  chk(bn256_bases_upload(ctx, raw.data() + 64 * (size_t)n, (size_t)n, 0, &h));
+  p.H = DevPoints(ctx, h);
+  memcpy(p.U.b, &raw[64 * (size_t)(2 * n)], 64);
+  memcpy(p.g.b, &raw[64 * (size_t)(2 * n + 1)], 64);
+  memcpy(p.h.b, &raw[64 * (size_t)(2 * n + 2)], 64);
   return p;
 }
 
