@@ -1108,7 +1108,7 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
   xyzz_mem* xs = nullptr;
-  if (n && !broadcast && (rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
+  if (n && !broadcast && (rc = xyzz_scratch(ctx, n <= SCALAR_MUL_QUAD_MAX ? 2 * n : n, &xs))) { bn256_bases_free(ctx, r); return rc; }
   if (n && broadcast) {
     // one scalar for every point (vectorPointMulOnScalar): the uniform NAF chain of the fold kernel
     static const uint8_t zero[32] = {0};
@@ -1125,10 +1125,11 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
     if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) { bn256_bases_free(ctx, r); return rc; }
     hipError_t e = hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      if (n <= SCALAR_MUL_QUAD_MAX)
-        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream,
+      if (n <= SCALAR_MUL_QUAD_MAX) {  // two GLV half-chains per point, then out[i] + phi(out[n + i])
+        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream,
                            (const aff_mem*)(in->d + off), (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
-      else
+        hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
+      } else
         hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(in->d + off),
                            (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
       normalize_into(ctx, xs, r->d, n);
@@ -1324,7 +1325,7 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
     hostg1::be_store(g0 + 32, y);
     xyzz_mem* xs = nullptr;
     if ((rc = ws_reserve(ctx, WS_TMP, 64 + sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, n * 32)) ||
-        (rc = xyzz_scratch(ctx, n, &xs))) {
+        (rc = xyzz_scratch(ctx, n <= SCALAR_MUL_QUAD_MAX ? 2 * n : n, &xs))) {
       bn256_bases_free(ctx, b);
       return rc;
     }
@@ -1336,10 +1337,11 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
       hipLaunchKernelGGL(k_points_from_be, dim3(1), dim3(256), 0, ctx->stream, (const uint8_t*)tmp, d_g0, 1u, ctx->d_err);
       hipLaunchKernelGGL(k_synth_scalars, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
                          (uint8_t*)ctx->ws[WS_SCALARS], (u64)seed, (u64)first, (u32)n, 1u);
-      if (n <= SCALAR_MUL_QUAD_MAX)
-        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
+      if (n <= SCALAR_MUL_QUAD_MAX) {
+        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
                            (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
-      else
+        hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
+      } else
         hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
                            (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
       normalize_into(ctx, xs, b->d, n);

@@ -87,6 +87,89 @@ __device__ __forceinline__ u32 sel8(const u32 k[8], u32 j) {
   for (int i = 0; i < 8; i++) r = (j == (u32)i) ? k[i] : r;
   return r;
 }
+// ---- GLV split on the device (the host's glv_split in bn256msm.hip restated with 32-bit words) ----
+// m < n  ->  m = k1 + k2 lambda (mod n), |k1|, |k2| < 2^129; (beta x, y) = lambda (x, y) on G1.
+// c1 = (m G1) >> 384 ~ m B2 / n, c2 = (m G2) >> 384 ~ m B1 / n;  k1 = m - c1 A1 - c2 B1,
+// k2 = c2 B2 - c1 B1, both exact in two's complement; a quotient that is off by one only moves
+// (k1, k2) by one (short) basis vector.
+template <int NA, int NB, int NR>
+__device__ __forceinline__ void words_mul(u32 (&r)[NR], const u32 (&a)[NA], const u32 (&b)[NB]) {
+#pragma unroll
+  for (int i = 0; i < NR; i++) r[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; i++) {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      if (i + j < NR) {
+        c += (u64)a[i] * b[j] + r[i + j];
+        r[i + j] = (u32)c;
+        c >>= 32;
+      }
+    }
+#pragma unroll
+    for (int t = i + NB; t < NR; t++) {
+      c += r[t];
+      r[t] = (u32)c;
+      c >>= 32;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void words_sub(u32 (&r)[N], const u32 (&a)[N]) {  // r -= a (mod 2^(32 N))
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    u64 d = (u64)r[i] - a[i] - br;
+    r[i] = (u32)d;
+    br = (d >> 32) & 1;
+  }
+}
+// two's complement (N words) -> magnitude in 5 words, returns the sign
+template <int N>
+__device__ __forceinline__ bool words_abs5(u32 (&m)[5], const u32 (&v)[N]) {
+  bool neg = (v[N - 1] >> 31) != 0;
+  u64 c = neg ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    c += neg ? (u32)~v[i] : v[i];
+    m[i] = (u32)c;
+    c >>= 32;
+  }
+  return neg;
+}
+__device__ __forceinline__ void glv_split_dev(const u32 (&m)[8], u32 (&k1)[5], bool& n1, u32 (&k2)[5], bool& n2) {
+  const u32 A1[4] = {0xb7be300bu, 0x6808727cu, 0x288a7c7bu, 0xbfcdfabeu};
+  const u32 B1[2] = {0xd8b10603u, 0xb4ed5d35u};
+  const u32 B2[4] = {0xdf0d2a08u, 0xb31b1546u, 0x288a7c7au, 0xbfcdfabeu};
+  const u32 G1[9] = {0xbdbf1528u, 0x60ee1bc8u, 0x8a2a05c0u, 0xe21d18f2u, 0x7c4a4445u, 0xae13553cu,
+                     0xffd56e3du, 0x55ae596cu, 1u};
+  const u32 G2[7] = {0x8c26a0b7u, 0x369d8675u, 0x653eef7bu, 0x287e2fc7u, 0x740d1660u, 0x424dd4afu, 1u};
+  u32 t17[17], t15[15];
+  words_mul<8, 9, 17>(t17, m, G1);
+  words_mul<8, 7, 15>(t15, m, G2);
+  const u32 c1[5] = {t17[12], t17[13], t17[14], t17[15], t17[16]};
+  const u32 c2[3] = {t15[12], t15[13], t15[14]};
+  u32 v1[9], v2[9], u[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) v1[i] = i < 8 ? m[i] : 0u;
+  words_mul<5, 4, 9>(u, c1, A1);
+  words_sub<9>(v1, u);
+  words_mul<3, 2, 9>(u, c2, B1);
+  words_sub<9>(v1, u);
+  words_mul<3, 4, 9>(v2, c2, B2);
+  words_mul<5, 2, 9>(u, c1, B1);
+  words_sub<9>(v2, u);
+  n1 = words_abs5<9>(k1, v1);
+  n2 = words_abs5<9>(k2, v2);
+}
+__device__ __forceinline__ u32 sel5(const u32 (&k)[5], u32 j) {
+  u32 r = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) r = (j == (u32)i) ? k[i] : r;
+  return r;
+}
+
 __device__ __forceinline__ u32 scalar_bits(const u32 k[8], u32 bit, u32 width) {
   u32 j = bit >> 5, s = bit & 31;
   u64 v = (u64)sel8(k, j) | ((u64)sel8(k, j + 1) << 32);
@@ -927,21 +1010,43 @@ __global__ void __launch_bounds__(256) k_precompute_level(const aff_mem* __restr
 }
 
 // ------------------------------------------------------------------ element-wise point ops
-// acc = k * (x, y), MSB-first double-and-add on the signed representative of k.
-__device__ __forceinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& y_in, u32 k[8]) {
-  bool neg = scalar_reduce_signed(k);
-  fe y = neg ? fe_neg(y_in) : y_in;
+// acc = k * (x, y).  The signed representative of k is split by the endomorphism,
+// |k| = k1 + k2 lambda with |k1|, |k2| < 2^129 (glv_split_dev), and one MSB-first joint
+// double-and-add runs over A = +-P, B = +-phi(P) = (beta x, +-y) and A + B: 130 doublings and ~97
+// additions (A, B mixed; A + B general) instead of 255 and ~128.
+__device__ __forceinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& y_in, u32 (&k)[8]) {
+  const bool neg = scalar_reduce_signed(k);
+  u32 k1[5], k2[5];
+  bool n1, n2;
+  glv_split_dev(k, k1, n1, k2, n2);
+  const fe beta = {FE_BETA_LIMBS};
+  const fe bx = fe_mul(x, beta);
+  const fe ya = (neg != n1) ? fe_neg(y_in) : y_in, yb = (neg != n2) ? fe_neg(y_in) : y_in;
+  xyzz ab;
+  xyzz_from_affine(ab, x, fe_norm(ya));
+  xyzz_madd(ab, bx, yb);  // A + B (A == -B cannot happen: beta != 1; A == B neither)
   xyzz_set_inf(acc);
-  bool started = false;
-  for (int bit = 254; bit >= 0; bit--) {
-    if (started) {
+  const fe one = fe_one();
+  for (int bit = 129; bit >= 0; bit--) {
+    if (!xyzz_is_inf(acc)) {
       xyzz r;
       xyzz_dbl(r, acc);
       acc = r;
     }
-    if ((sel8(k, (u32)bit >> 5) >> (bit & 31)) & 1u) {
-      xyzz_madd(acc, x, y);
-      started = true;
+    const u32 b1 = (sel5(k1, (u32)bit >> 5) >> (bit & 31)) & 1u, b2 = (sel5(k2, (u32)bit >> 5) >> (bit & 31)) & 1u;
+    // the lanes of a wave need different operands: one general addition with a selected operand
+    // (A, B as XYZZ with ZZ = ZZZ = 1) instead of three divergent paths
+    if (b1 | b2) {
+      xyzz T, r;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        T.x.v[j] = (b1 & b2) ? ab.x.v[j] : (b1 ? x.v[j] : bx.v[j]);
+        T.y.v[j] = (b1 & b2) ? ab.y.v[j] : (b1 ? ya.v[j] : yb.v[j]);
+        T.zz.v[j] = (b1 & b2) ? ab.zz.v[j] : one.v[j];
+        T.zzz.v[j] = (b1 & b2) ? ab.zzz.v[j] : one.v[j];
+      }
+      xyzz_add(r, acc, T);
+      acc = r;
     }
   }
 }
@@ -964,32 +1069,43 @@ __global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ 
 }
 
 // The same for few points (the provers' small vectors: a call is one latency chain, not throughput
-// work): one quad per point, quad-cooperative doubling / addition, 2-bit windows over {P, 2P, 3P} --
-// 256 doublings + <= 128 additions in 3 + 4 multiplication stages each instead of 255 x (doubling +
-// addition) executed serially by one lane.
+// work): one quad per point and GLV half, quad-cooperative doubling / addition, 2-bit windows over
+// {P, 2P, 3P} -- 130 doublings + <= 65 additions in 3 + 4 multiplication stages each instead of
+// 255 x (doubling + addition) executed serially by one lane.
 __global__ void __launch_bounds__(256) k_scalar_mul_quad(const aff_mem* __restrict__ in,
                                                          const uint8_t* __restrict__ scalars_be,
                                                          xyzz_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
                                                          u32 broadcast_point) {
+  // GLV as in k_fold_points_quad: blockIdx.y = 0 computes k1 * P into out[i], blockIdx.y = 1 computes
+  // k2 * P into out[n + i] (|k| = k1 + k2 lambda, glv_split_dev); k_glv_combine adds out[i] + phi(out[n + i])
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   u32 i = gid >> 2, role = gid & 3u;
   if (i >= n) return;  // whole quads leave together
+  out += (size_t)blockIdx.y * n;
   fe x, y;
   xyzz acc;
   xyzz_set_inf(acc);
   if (aff_load(x, y, &in[broadcast_point ? 0 : i], false)) {
-    u32 k[8];
+    u32 k[8], k1[5], k2[5];
+    bool n1, n2;
     scalar_load_be(k, scalars_be + (broadcast_scalar ? 0 : (size_t)i * 32));
     bool neg = scalar_reduce_signed(k);
+    glv_split_dev(k, k1, n1, k2, n2);
+    if (blockIdx.y) {
+#pragma unroll
+      for (int j = 0; j < 5; j++) k1[j] = k2[j];
+      n1 = n2;
+    }
+    neg = neg != n1;
     xyzz P1, P2, P3;
     xyzz_from_affine(P1, x, fe_norm(neg ? fe_neg(y) : y));
     xyzz_dbl_quad(P2, P1, role);
     xyzz_add_quad(P3, P2, P1, role);
-    for (int w = 127; w >= 0; w--) {
+    for (int w = 64; w >= 0; w--) {  // 130 bits
       xyzz t;
       xyzz_dbl_quad(t, acc, role);
       xyzz_dbl_quad(acc, t, role);
-      u32 d = (sel8(k, (u32)(2 * w) >> 5) >> ((2 * w) & 31)) & 3u;
+      u32 d = (sel5(k1, (u32)(2 * w) >> 5) >> ((2 * w) & 31)) & 3u;
       if (d == 0) continue;  // uniform within the quad
       xyzz T = d == 1 ? P1 : (d == 2 ? P2 : P3);
       xyzz_add_quad(t, acc, T, role);
