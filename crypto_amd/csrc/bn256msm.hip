@@ -1180,7 +1180,7 @@ extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const 
   if (!r) { bn256_bases_free(ctx, pts); return rc; }
   if (n) {
     xyzz_mem* xs = nullptr;
-    if ((rc = xyzz_scratch(ctx, n, &xs)) || (rc = ws_reserve(ctx, WS_SCALARS, 2 * n * 32))) {
+    if ((rc = xyzz_scratch(ctx, 2 * n, &xs)) || (rc = ws_reserve(ctx, WS_SCALARS, 2 * n * 32))) {
       bn256_bases_free(ctx, pts);
       bn256_bases_free(ctx, r);
       return rc;
@@ -1189,8 +1189,9 @@ extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const 
     hipError_t e = hipMemcpyAsync(ds, a_be, n * 32, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ds + n * 32, b_be, n * 32, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_com_batch_quad, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)pts->d,
+      hipLaunchKernelGGL(k_com_batch_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, (const aff_mem*)pts->d,
                          (const uint8_t*)ds, (const uint8_t*)(ds + n * 32), xs, (u32)n);
+      hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
       normalize_into(ctx, xs, r->d, n);
       e = hipStreamSynchronize(ctx->stream);
     }

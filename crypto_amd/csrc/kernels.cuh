@@ -1286,26 +1286,47 @@ __global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restric
 __global__ void __launch_bounds__(256) k_com_batch_quad(const aff_mem* __restrict__ gh, const uint8_t* __restrict__ a_be,
                                                         const uint8_t* __restrict__ b_be, xyzz_mem* __restrict__ out,
                                                         u32 n) {
+  // GLV as in k_scalar_mul_quad: blockIdx.y = 0 runs (a1, b1) into out[i], blockIdx.y = 1 runs (a2, b2)
+  // into out[n + i], a = a1 + a2 lambda, b = b1 + b2 lambda; k_glv_combine joins them.  The signs
+  // of the two halves go into the points: P = +-g, Q = +-h.
   u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
   u32 i = gid >> 2, role = gid & 3u;
   if (i >= n) return;
+  out += (size_t)blockIdx.y * n;
+  u32 k[8], ka[5], kb[5], t5[5];
+  bool na, nb, nt;
+  scalar_load_be(k, a_be + (size_t)i * 32);
+  bool neg = scalar_reduce_signed(k);
+  glv_split_dev(k, ka, na, t5, nt);
+  if (blockIdx.y) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) ka[j] = t5[j];
+    na = nt;
+  }
+  na = na != neg;
+  scalar_load_be(k, b_be + (size_t)i * 32);
+  neg = scalar_reduce_signed(k);
+  glv_split_dev(k, kb, nb, t5, nt);
+  if (blockIdx.y) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) kb[j] = t5[j];
+    nb = nt;
+  }
+  nb = nb != neg;
   fe x, y;
   xyzz P, Q, S, acc;
   xyzz_set_inf(P);
   xyzz_set_inf(Q);
-  if (aff_load(x, y, &gh[0], false)) xyzz_from_affine(P, x, y);
-  if (aff_load(x, y, &gh[1], false)) xyzz_from_affine(Q, x, y);
+  if (aff_load(x, y, &gh[0], na)) xyzz_from_affine(P, x, y);
+  if (aff_load(x, y, &gh[1], nb)) xyzz_from_affine(Q, x, y);
   xyzz_add_quad(S, P, Q, role);
-  u32 ka[8], kb[8];
-  scalar_load_be(ka, a_be + (size_t)i * 32);  // any 256-bit integer works: n * P = infinity
-  scalar_load_be(kb, b_be + (size_t)i * 32);
   xyzz_set_inf(acc);
-  for (int bit = 255; bit >= 0; bit--) {
+  for (int bit = 129; bit >= 0; bit--) {
     xyzz t;
     xyzz_dbl_quad(t, acc, role);
     acc = t;
-    u32 da = (sel8(ka, (u32)bit >> 5) >> (bit & 31)) & 1u;
-    u32 db = (sel8(kb, (u32)bit >> 5) >> (bit & 31)) & 1u;
+    u32 da = (sel5(ka, (u32)bit >> 5) >> (bit & 31)) & 1u;
+    u32 db = (sel5(kb, (u32)bit >> 5) >> (bit & 31)) & 1u;
     if ((da | db) == 0) continue;
     xyzz T = (da & db) ? S : (da ? P : Q);
     xyzz_add_quad(t, acc, T, role);
