@@ -901,7 +901,7 @@ extern "C" int bn256_msm_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* 
 static size_t fold_quad_max() {
   static const size_t v = [] {
     const char* e = getenv("BN256_FOLD_QUAD_MAX");
-    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)28672;  // measured crossover: quad 1.0 ms at 2^14, 1.7 at 2^15; lane 1.6 flat to 2^16
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)24576;  // measured crossover: quad 1.0 ms at 2^14, 1.7 at 2^15; lane 1.34 ms flat to 2^16
   }();
   return v;
 }
@@ -1084,15 +1084,16 @@ static int fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32
     hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, lo, hi, stride, jsf[0],
                        jsf[1], xs, n_lo, n_hi);
     hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
-  } else {
+  } else if (quad) {  // one full-length chain (grid.y = 1: the second argument is never read)
     jsf_arg jsf;
     jsf_build(s_lo_be, s_hi_be, &jsf);
-    if (quad)  // one full-length chain (grid.y = 1: the second argument is never read)
-      hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256), 1), dim3(256), 0, ctx->stream, lo, hi, stride, jsf,
-                         jsf, xs, n_lo, n_hi);
-    else
-      hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf, xs, n_lo,
-                         n_hi);
+    hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256), 1), dim3(256), 0, ctx->stream, lo, hi, stride, jsf,
+                       jsf, xs, n_lo, n_hi);
+  } else {  // both GLV halves on one doubling chain
+    jsf_arg jsf[2];
+    jsf_build_glv(s_lo_be, s_hi_be, jsf);
+    hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf[0], jsf[1], xs,
+                       n_lo, n_hi);
   }
   *xs_out = xs;
   return BN256_OK;

@@ -1223,8 +1223,11 @@ __global__ void __launch_bounds__(256) k_glv_combine(xyzz_mem* __restrict__ out,
 // multiplications per digit and enough waves per SIMD to issue back to back.  P, Q stay affine
 // (mixed additions), P+Q and P-Q stay XYZZ (general additions).
 __global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
-                                                     u32 stride, jsf_arg jsf, xyzz_mem* __restrict__ out, u32 n_lo,
-                                                     u32 n_hi) {
+                                                        u32 stride, jsf_arg jsf0, jsf_arg jsf1,
+                                                        xyzz_mem* __restrict__ out, u32 n_lo, u32 n_hi) {
+  // GLV with ONE shared doubling chain (throughput, not latency, is what counts here): jsf0 holds
+  // the digits of (s_lo', s_hi'), jsf1 those of (s_lo'', s_hi''), s = s' + s'' lambda; a digit of
+  // jsf1 adds phi(T) = (beta X, Y, ZZ, ZZZ) of the same table entry T.  130 doublings instead of 257.
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   u32 n = n_lo > n_hi ? n_lo : n_hi;
   if (i >= n) return;
@@ -1247,34 +1250,43 @@ __global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restric
       sd[which][27 + k][threadIdx.x] = acc.zzz.v[k];
     }
   }
+  const fe beta = {FE_BETA_LIMBS};
   xyzz_set_inf(acc);
-  for (int j = (int)jsf.len - 1; j >= 0; j--) {
+  const int len = (int)(jsf0.len > jsf1.len ? jsf0.len : jsf1.len);
+  for (int j = len - 1; j >= 0; j--) {
     {
       xyzz t;
       xyzz_dbl(t, acc);
       acc = t;
     }
-    u32 d = (jsf.w[j >> 3] >> ((j & 7) * 4)) & 15u;
-    if (d == 0) continue;  // uniform over the grid
-    u32 d0 = d & 3u, d1 = d >> 2;
-    bool neg = (d0 ? d0 : d1) == 3u;
-    if (d1 == 0) {
-      if (hp) xyzz_madd(acc, px, neg ? fe_neg(py) : py);
-    } else if (d0 == 0) {
-      if (hq) xyzz_madd(acc, qx, neg ? fe_neg(qy) : qy);
-    } else {
-      const u32 which = d0 == d1 ? 0u : 1u;
-      xyzz T, r;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {  // h = 1: the phi half
+      const u32 d = ((h ? jsf1.w[j >> 3] : jsf0.w[j >> 3]) >> ((j & 7) * 4)) & 15u;  // words beyond len are zero
+      if (d == 0) continue;  // uniform over the grid
+      const u32 d0 = d & 3u, d1 = d >> 2;
+      const bool neg = (d0 ? d0 : d1) == 3u;
+      if (d1 == 0 || d0 == 0) {
+        const bool useq = d1 != 0;
+        if (useq ? hq : hp) {
+          fe tx = useq ? qx : px, ty = useq ? qy : py;
+          if (h) tx = fe_mul(tx, beta);
+          xyzz_madd(acc, tx, neg ? fe_neg(ty) : ty);
+        }
+      } else {
+        const u32 which = d0 == d1 ? 0u : 1u;
+        xyzz T, r;
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
-        T.x.v[k] = sd[which][k][threadIdx.x];
-        T.y.v[k] = sd[which][9 + k][threadIdx.x];
-        T.zz.v[k] = sd[which][18 + k][threadIdx.x];
-        T.zzz.v[k] = sd[which][27 + k][threadIdx.x];
+        for (int k = 0; k < 9; k++) {
+          T.x.v[k] = sd[which][k][threadIdx.x];
+          T.y.v[k] = sd[which][9 + k][threadIdx.x];
+          T.zz.v[k] = sd[which][18 + k][threadIdx.x];
+          T.zzz.v[k] = sd[which][27 + k][threadIdx.x];
+        }
+        if (h) T.x = fe_mul(T.x, beta);
+        if (neg) T.y = fe_neg(T.y);
+        xyzz_add(r, acc, T);
+        acc = r;
       }
-      if (neg) T.y = fe_neg(T.y);
-      xyzz_add(r, acc, T);
-      acc = r;
     }
   }
   xyzz_store(&out[i], acc);

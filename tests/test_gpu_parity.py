@@ -272,7 +272,7 @@ def test_fold_submit_wait(eng, orc):
 
 
 def test_fold_lane_per_output_kernel(eng, orc):
-    """Generator folds of more than 28672 outputs run one lane per output (k_fold_points), up to 2^13
+    """Generator folds of more than 24576 outputs run one lane per output (k_fold_points), up to 2^13
     outputs two GLV half-chains of one quad per output, in between one quad over the full chain: the
     three against one another (the whole result against <= 2^13-point pieces), edge cases
     and a sample against the oracle (go/bp/main.go:355-356, vectorPointsAdd padding go/bppp/util.go:279-293)."""
@@ -294,7 +294,7 @@ def test_fold_lane_per_output_kernel(eng, orc):
         for off in range(0, n, 1 << 13):
             want += eng.fold(lo, off, hi, off, min(1 << 13, n - off), a, b).download()
         assert got == want
-        # 2^13 < outputs <= 28672: one quad per output over the full-length chain
+        # 2^13 < outputs <= 24576: one quad per output over the full-length chain
         assert eng.fold(lo, 0, hi, 0, 1 << 14, a, b).download() == want[:1 << 14]
         for i in (0, 3, 5, 7, 9, 11, 64, 255, 256, 8191, 16384, 32768, n - 1):
             assert got[i] == orc.add(orc.mul(lo_raw[i], a), orc.mul(hi_raw[i], b)), i
