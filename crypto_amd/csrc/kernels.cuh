@@ -1409,6 +1409,44 @@ __global__ void __launch_bounds__(256) k_selftest(u32* __restrict__ errs, u32 n)
     fe f1 = fe_canon(fe_mul2add(d1, d2, fe_neg(a), b)), f2 = fe_canon(fe_sub(fe_mul(d1, d2), fe_mul(a, b)));
     for (int j = 0; j < 9; j++) bad |= (f1.v[j] != f2.v[j]) ? 128u : 0u;
   }
+  // device GLV split: |k1|, |k2| < 2^129 and k1 + k2 lambda == m (mod n), m the signed representative
+  {
+    u32 m[8], k1[5], k2[5];
+#pragma unroll
+    for (int j = 0; j < 8; j++) m[j] = wb[j];
+    if (i == 2) { for (int j = 0; j < 8; j++) m[j] = 0xffffffffu; }
+    if (i == 3) { for (int j = 0; j < 8; j++) m[j] = fr_n_word(j) - (j == 0 ? 1u : 0u); }
+    if (i == 4) { for (int j = 0; j < 8; j++) m[j] = fr_half_word(j); }
+    if (i == 5) { for (int j = 0; j < 8; j++) m[j] = 0; }
+    scalar_reduce_signed(m);
+    bool n1, n2;
+    glv_split_dev(m, k1, n1, k2, n2);
+    if (k1[4] > 1u || k2[4] > 1u) bad |= 512u;
+    const u32 lamw[8] = {0x264ac23du, 0x3be518b5u, 0xf8bfcd51u, 0xcf9176e4u, 0x07e9f9eeu, 0x96ac037fu, 0x1u, 0u};
+    fr f1 = fr_zero(), f2 = fr_zero(), lam, fm;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      lam.w[j] = lamw[j];
+      fm.w[j] = m[j];
+      if (j < 5) {
+        f1.w[j] = k1[j];
+        f2.w[j] = k2[j];
+      }
+    }
+    fr t = fr_mont(fr_to_mont(f2), lam);  // k2 * lambda mod n
+    auto fneg = [](const fr& v) {
+      u32 nn[8], o[8], any = 0;
+      for (int j = 0; j < 8; j++) { nn[j] = fr_n_word(j); any |= v.w[j]; }
+      u256_sub(o, nn, v.w);
+      fr q;
+      for (int j = 0; j < 8; j++) q.w[j] = any ? o[j] : 0u;
+      return q;
+    };
+    if (n1) f1 = fneg(f1);
+    if (n2) t = fneg(t);
+    fr sum = fr_add(f1, t);
+    for (int j = 0; j < 8; j++) bad |= (sum.w[j] != fm.w[j]) ? 1024u : 0u;
+  }
   // associativity and distributivity
   fe l = fe_canon(fe_mul(fe_mul(a, b), c)), r = fe_canon(fe_mul(a, fe_mul(b, c)));
   for (int j = 0; j < 9; j++) bad |= (l.v[j] != r.v[j]) ? 4u : 0u;
