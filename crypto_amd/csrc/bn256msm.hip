@@ -597,7 +597,9 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
     }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], s));
-    hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 256)), dim3(256), 0, s, (const aff_mem*)b->d, (const u32*)sval,
+    // 128-thread workgroups: the same single round of waves, placed and retired in finer units
+    // (measured 1.051 -> 1.031 ms at 2^20; 64 threads the same, limiting residency by LDS slower)
+    hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
                        (const u32*)offsets, (u32)nbt, K, buckets, partials);
     HIPCHK(hipEventRecord(ctx->ev[4], s));
     hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
