@@ -191,6 +191,16 @@ def main():
                 "whole_msm_frac": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK,
             },
         }
+        if not args.no_precompute and n >= (1 << 18):
+            # HBM rate of the sort / scatter phases (two-pass sort, 16 windows): ALGORITHMIC bytes -- 32-byte
+            # scalars in, one 4-byte record per (point, window) out, then records in, sorted entries out --
+            # over the live phase times; the PMC counters are in profiles/ and DESIGN.md 6
+            ent = 16 * n * 4
+            line["sort_hbm"] = {
+                "pass_a": {"bytes": 32 * n + ent, "ms": phase[0], "GB/s": (32 * n + ent) / (phase[0] * 1e-3) / 1e9},
+                "pass_b": {"bytes": 2 * ent, "ms": phase[2], "GB/s": 2 * ent / (phase[2] * 1e-3) / 1e9},
+                "peak_GB/s": 8000.0,
+            }
         if world == 1 and not args.no_cpu_baseline:
             v, _, orc = cpu_baseline(args.cpu_sample)
             # the oracle as checker: exact answer of the whole timed workload from its closed form
