@@ -271,6 +271,46 @@ def test_fold_submit_wait(eng, orc):
     assert len(e) == 0
 
 
+def test_glv_paths_randomised_against_oracle(eng, orc):
+    """The endomorphism-split kernels (per-point scalars, shared-scalar folds, 2-term commitments) on
+    seeded random sizes and scalars of every bit length -- including 0, 1, n-1, values >= n and
+    scalars whose GLV halves are tiny or change sign -- against the oracle's double-and-add."""
+    import random
+    rng = random.Random(0x61C)
+    lam = 0x196ac037f07e9f9eecf9176e4f8bfcd513be518b5264ac23d
+    special = [0, 1, 2, N_ORDER - 1, N_ORDER, N_ORDER + 1, 2**256 - 1, lam, lam + 1, N_ORDER - lam, (N_ORDER - 1) // 2,
+               (N_ORDER + 1) // 2, 2**128, 2**129 - 1, 2**64, 3 * lam % N_ORDER]
+
+    def rscalar():
+        r = rng.random()
+        if r < 0.25:
+            return rng.choice(special)
+        return rng.randrange(2 ** rng.randrange(1, 257))
+
+    for trial in range(10):
+        n = rng.choice([1, 2, 3, 5, 17, 64, 129, 255])
+        braw = eng.random_bases(0x700 + trial, 2 * n).download()
+        if trial % 3 == 0:
+            braw[rng.randrange(2 * n)] = INF
+        g = eng.upload(braw)
+        ks = [rscalar() for _ in range(n)]
+        want = orc.scalar_mul_each(b"".join(braw[:n]), b"".join((k % 2**256).to_bytes(32, "big") for k in ks))
+        assert b"".join(eng.scalar_mul_each(g, ks).download()) == want, trial
+        a, b = rscalar(), rscalar()
+        got = eng.fold(g, 0, g, n, n, a, b).download()
+        wa = orc.scalar_mul_each(b"".join(braw[:n]), a.to_bytes(32, "big"), broadcast=True)
+        wb = orc.scalar_mul_each(b"".join(braw[n:]), b.to_bytes(32, "big"), broadcast=True)
+        assert b"".join(got) == orc.add_each(wa, wb), trial
+        assert b"".join(eng.vector_point_mul_on_scalar(g, a, 0, n).download()) == wa, trial
+        p0, p1 = braw[0], braw[n]
+        if p0 != INF and p1 != INF:
+            aa, bb = [rscalar() for _ in range(n)], [rscalar() for _ in range(n)]
+            gotc = eng.com_batch(p0, p1, aa, bb).download()
+            w0 = orc.scalar_mul_each(p0 * n, b"".join(x.to_bytes(32, "big") for x in aa))
+            w1 = orc.scalar_mul_each(p1 * n, b"".join(x.to_bytes(32, "big") for x in bb))
+            assert b"".join(gotc) == orc.add_each(w0, w1), trial
+
+
 def test_fold_lane_per_output_kernel(eng, orc):
     """Generator folds of more than 24576 outputs run one lane per output (k_fold_points), up to 2^13
     outputs two GLV half-chains of one quad per output, in between one quad over the full chain: the
