@@ -103,6 +103,15 @@ def test_wnla_2_16_commitment_vectors(wnla):
     assert r["ok"] and r["rounds"] >= 14
 
 
+def test_wnla_2_20_commitment_vectors(wnla):
+    """BASELINE.json configs[3] at its full size (|l| = 2^20, |n| = 2^19): 19 rounds with the X / R
+    MSMs on two lanes, the lane-per-output fold kernel in the first rounds and the quad kernels after;
+    the argument's final check (go/bppp/docs_test.go:1273-1288) must close, twice in one context."""
+    for seed in (0xABCD, 0xABCE):
+        r = wnla.synthetic(seed, 1 << 20, 1 << 19)
+        assert r["ok"] and r["rounds"] == 19
+
+
 def test_strided_msm_and_ragged_fold(eng, orc):
     n = 37
     braw = orc.synth_bases(0x51, n)
