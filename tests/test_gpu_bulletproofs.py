@@ -56,6 +56,17 @@ def test_range_proof_64_bit_random_values(bp):
         assert bp.verify(64, seed, raw) is None
 
 
+def test_range_proof_other_bit_lengths(bp):
+    """Prove -> Verify at n = 2, 16, 128 and 256 bits (one and eight inner-product levels; the reference's
+    own check is this round trip, go/bp/main_test.go:30-35): accepted, and a value outside the range or
+    a proof for another parameter set is rejected."""
+    for n, v, seed in [(2, 3, 11), (16, 0xBEEF, 12), (128, (1 << 128) - 5, 13), (256, (1 << 255) + 12345, 14)]:
+        raw = bp.prove(n, v, seed)
+        assert bp.verify(n, seed, raw) is None, n
+        assert bp.verify(n, seed + 1, raw) is not None, n  # other generators
+    assert bp.verify(16, 21, bp.prove(16, 1 << 16, 21)) is not None  # 2^16 does not fit 16 bits
+
+
 def test_inner_product_argument(bp):
     """go/bp/docs_test.go:381-392 inputs (n = 4); the reference's TestInnerProduct (n = 8 with
     length-4 vectors) panics with "invalid length" there, see SURVEY.md section 4."""
