@@ -129,8 +129,6 @@ struct bn256_ctx {
   int tune_c, tune_k;
   size_t msm_chunk;  // 0 = MSM_CHUNK; BN256_MSM_CHUNK_LOG2 in the environment overrides (experiments)
   int sort1;         // BN256_SORT1=1 forces the single-pass sort (experiments)
-  int lds_attr2_set;
-  int lds_attr_set;
   u32* h_pack;      // pinned
   size_t h_pack_cap;
   u32* d_err;
@@ -178,6 +176,46 @@ extern "C" const char* bn256_strerror(int code) {
   }
 }
 
+// Everything bn256_ctx_create made, in reverse; `counted` = pool::context_created() has run.  Also the
+// failure path of bn256_ctx_create, so that a half-built context is not leaked.
+static void pending_free(struct msm_pending* p);
+static void ctx_teardown(bn256_ctx* ctx, bool counted) {
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < BN256_ASYNC_LANES; i++) {
+    pending_free(ctx->pending[i]);
+    bn256_ctx_destroy(ctx->lane[i]);
+  }
+  for (int i = 0; i < WS_COUNT; i++)
+    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->d_err) (void)hipFree(ctx->d_err);
+  if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
+  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+  if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (counted) pool::context_destroyed();
+  delete ctx;
+}
+
+static int ctx_init(bn256_ctx* ctx) {
+  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipMalloc(&ctx->d_err, 256));
+  HIPCHK(hipMalloc(&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32)));
+  HIPCHK(hipHostMalloc(&ctx->h_err, 256));
+  ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
+  HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
+  // the sort kernels' dynamic LDS above 48 KiB (per function and device; set here so that no MSM
+  // call carries set-up work)
+  HIPCHK(hipFuncSetAttribute((const void*)k_part, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  return BN256_OK;
+}
+
 extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
   if (!out) return BN256_EINVAL;
   *out = nullptr;
@@ -195,38 +233,19 @@ extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
     int lg = atoi(e);
     if (lg >= 10 && lg <= 30) ctx->msm_chunk = (size_t)1 << lg;
   }
-  HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
-  HIPCHK(hipMalloc(&ctx->d_err, 256));
-  HIPCHK(hipMalloc(&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32)));
-  HIPCHK(hipHostMalloc(&ctx->h_err, 256));
-  ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
-  HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
+  int rc = ctx_init(ctx);
+  if (rc) {
+    ctx_teardown(ctx, false);
+    return rc;
+  }
   pool::context_created();
   *out = ctx;
   return BN256_OK;
 }
 
-static void pending_free(struct msm_pending* p);
 extern "C" void bn256_ctx_destroy(bn256_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (int i = 0; i < BN256_ASYNC_LANES; i++) {
-    pending_free(ctx->pending[i]);
-    bn256_ctx_destroy(ctx->lane[i]);
-  }
-  for (int i = 0; i < WS_COUNT; i++)
-    if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
-  for (auto& e : ctx->ev)
-    if (e) (void)hipEventDestroy(e);
-  if (ctx->d_err) (void)hipFree(ctx->d_err);
-  if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
-  if (ctx->h_err) (void)hipHostFree(ctx->h_err);
-  if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  pool::context_destroyed();
-  delete ctx;
+  ctx_teardown(ctx, true);
 }
 
 extern "C" void* bn256_ctx_stream(bn256_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -451,8 +470,11 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
     return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
   };
   const u32 tiles2_max = tiles2_for(nmax);
+  // a pass uses it only with >= 2^18 points with a table, 2^19 without: below, the fixed costs of the
+  // 2^9..2^10 groups dominate
+  const size_t two_min = (size_t)1 << (precomp ? 18 : 19);
   const bool two_pass = c == 16 && nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
-                        entries_max <= (unsigned long long)G2 * 32768 &&
+                        nmax >= two_min && entries_max <= (unsigned long long)G2 * 32768 &&
                         (precomp ? wbits + ibits + 1 + LB2 <= 32 : ibits + 1 + LB2 <= 32);
   const size_t lds_part = ((size_t)2 * G2 + std::max<size_t>((size_t)16 * G2, SORT2_TCAP)) * 4;
   const size_t lds_gsort = ((size_t)(NH2 + 1) * (1u << LB2) + 2048 + SORT2_CAP) * 4;
@@ -464,19 +486,9 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
       return rc;
     if ((rc = ws_reserve(ctx, WS_GBASE, (size_t)tiles2_max * (G2 + 1) * 4))) return rc;  // loc[tile][0..G]
     if ((rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nbt * SORT2_S + 1) * 4))) return rc;
-    if (!ctx->lds_attr2_set) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_part, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-      ctx->lds_attr2_set = 1;
-    }
   }
   if (use_lds) {
     if (!two_pass && (rc = ws_reserve(ctx, WS_RANK, (size_t)nsets * want_tiles * nb * 4))) return rc;  // per-tile histograms
-    if (lds_bytes > 48 * 1024 && !ctx->lds_attr_set) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      ctx->lds_attr_set = 1;
-    }
   } else {
     if ((rc = ws_reserve(ctx, WS_RANK, entries_max * 4))) return rc;
   }
@@ -543,7 +555,7 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
     HIPCHK(hipMemsetAsync(heavy_count, 0, (2 + HEAVY_SLOTS + 1024) * sizeof(u32), s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
-    const bool two = two_pass && n_ch >= ((size_t)1 << (precomp ? 18 : 19));  // below: fixed costs of the 2^9..2^10 groups dominate
+    const bool two = two_pass && n_ch >= two_min;
     auto scan = [&](const u32* in, u32* out, size_t m) {
       u32 nblk = nblocks(m, SCAN_TILE);
       hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(SCAN_BLOCK), 0, s, in, out, (u32)m, blocksum);
