@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("BN256MSM_LIB") or os.path.join(_HERE, "libbn256msm.so
 
 EXPORTS = [
     "bn256_ctx_create", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
-    "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_submit", "bn256_msm_wait", "bn256_msm_multi", "bn256_msm_multi_strided", "bn256_fold2", "bn256_scalar_mul_batch",
+    "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_dev_noalloc", "bn256_msm_submit", "bn256_msm_wait", "bn256_msm_multi", "bn256_msm_multi_strided", "bn256_fold2", "bn256_scalar_mul_batch",
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
@@ -50,6 +50,7 @@ def load() -> C.CDLL:
     lib.bn256_bases_len.restype = sz
     lib.bn256_msm.argtypes = [vp, vp, sz, sz, u8p, u8p]
     lib.bn256_msm_dev.argtypes = [vp, vp, sz, sz, vp, u8p]
+    lib.bn256_msm_dev_noalloc.argtypes = [vp, vp, sz, sz, vp, u8p]
     lib.bn256_msm_submit.argtypes = [vp, vp, sz, sz, vp, C.POINTER(C.c_int)]
     lib.bn256_msm_wait.argtypes = [vp, C.c_int, u8p]
     lib.bn256_msm_multi.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p), u8p]

@@ -28,6 +28,31 @@ static void ctx_note_hip(hipError_t e, int line) {
   snprintf(g_hip_msg, sizeof g_hip_msg, "HIP error: %s (bn256msm.hip:%d)", hipGetErrorString(e), line);
 }
 
+// ---------------------------------------------------------------------------- static scratch
+// bn256_msm_dev_noalloc (include/bn256msm.h) runs the MSM pipeline without hipMalloc / hipFree: its
+// workspaces are carved from this array instead of the context's grow-only hipMalloc blocks.  Every
+// GPU the library runs on holds its own copy (at its own address) until the process ends.  In host
+// code the array's NAME is only a stand-in: the device address comes from hipGetSymbolAddress, once
+// per device (scratch_resolve, called by bn256_ctx_create with that device current), and only that
+// pointer is ever handed to kernels, memsets or copies.
+static __device__ __align__(256) unsigned char scratch[BN256_NOALLOC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static unsigned char* g_scratch_ptr[16];  // per HIP device ordinal; nullptr = not resolved yet
+
+static int scratch_resolve(int device) {
+  if (device < 0 || device >= 16) return BN256_OK;  // such a device simply has no allocation-free entry
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[device]) return BN256_OK;
+  void* ptr = nullptr;
+  hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));  // the current device's copy
+  if (e != hipSuccess || !ptr) {
+    ctx_note_hip(e != hipSuccess ? e : hipErrorInvalidSymbol, __LINE__);
+    return BN256_EHIP;
+  }
+  g_scratch_ptr[device] = (unsigned char*)ptr;
+  return BN256_OK;
+}
+
 // ---------------------------------------------------------------------------- handle memory
 // Handles (point sets, Fr vectors) come and go once per round in the provers' folding loops
 // (go/bp/main.go:355-358, go/bppp/docs_test.go:1318-1326): hipMalloc / hipFree cost 0.1 ms each and
@@ -129,6 +154,9 @@ struct bn256_ctx {
   int tune_c, tune_k;
   size_t msm_chunk;  // 0 = MSM_CHUNK; BN256_MSM_CHUNK_LOG2 in the environment overrides (experiments)
   int sort1;         // BN256_SORT1=1 forces the single-pass sort (experiments)
+  // bn256_msm_dev_noalloc: while set, ws_reserve carves ws[] from the device's static scratch array
+  bool fixed_ws;
+  size_t fixed_used;
   u32* h_pack;      // pinned
   size_t h_pack_cap;
   u32* d_err;
@@ -143,6 +171,14 @@ struct bn256_ctx {
 
 static int ws_reserve(bn256_ctx* ctx, int which, size_t bytes) {
   if (ctx->cap[which] >= bytes) return BN256_OK;
+  if (ctx->fixed_ws) {  // no hipMalloc / hipFree on this path: the next 256-byte aligned piece of the array
+    const size_t at = (ctx->fixed_used + 255) & ~(size_t)255;
+    if (bytes > BN256_NOALLOC_SCRATCH_BYTES || at > BN256_NOALLOC_SCRATCH_BYTES - bytes) return BN256_ESCRATCH;
+    ctx->ws[which] = g_scratch_ptr[ctx->device] + at;
+    ctx->cap[which] = bytes;
+    ctx->fixed_used = at + bytes;
+    return BN256_OK;
+  }
   if (ctx->ws[which]) {
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return BN256_EHIP;
     (void)hipFree(ctx->ws[which]);
@@ -172,6 +208,7 @@ extern "C" const char* bn256_strerror(int code) {
     case BN256_ENOMEM: return "out of device memory";
     case BN256_ETOOLARGE: return "problem too large (n * windows >= 2^31)";
     case BN256_EBUSY: return "every asynchronous lane holds a submitted call: wait for one first";
+    case BN256_ESCRATCH: return "bn256_msm_dev_noalloc: the call needs more workspace than the static scratch array holds (BN256_NOALLOC_SCRATCH_BYTES)";
     default: return "unknown error";
   }
 }
@@ -213,7 +250,7 @@ static int ctx_init(bn256_ctx* ctx) {
   HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-  return BN256_OK;
+  return scratch_resolve(ctx->device);  // this device's copy of the static scratch array
 }
 
 extern "C" int bn256_ctx_create(int device, bn256_ctx** out) {
@@ -708,6 +745,45 @@ extern "C" int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, s
   hostg1::Pt r;
   rc = msm_core(ctx, b, off, 1, n, (const uint8_t*)d_scalars_be, &r);
   if (rc) return rc;
+  hostg1::marshal(out_xy_be, r);
+  return BN256_OK;
+}
+
+// bn256_msm_dev without hipMalloc / hipFree: the same pipeline (msm_core) with every workspace carved
+// from this device's static scratch array instead of the context's hipMalloc blocks.
+extern "C" int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n,
+                                     const void* d_scalars_be, uint8_t out_xy_be[64]) {
+  if (!ctx || !b || !out_xy_be || (!d_scalars_be && n)) return BN256_EINVAL;
+  int rc = range_check(b, off, n);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->device < 0 || ctx->device >= 16 || !g_scratch_ptr[ctx->device]) return BN256_EINVAL;
+  // swap the workspace table for an empty one that ws_reserve fills from the array; whatever the
+  // outcome, the context's own blocks come back untouched
+  struct swap_ws {
+    bn256_ctx* c;
+    void* ws[WS_COUNT];
+    size_t cap[WS_COUNT];
+    explicit swap_ws(bn256_ctx* c_) : c(c_) {
+      memcpy(ws, c->ws, sizeof ws);
+      memcpy(cap, c->cap, sizeof cap);
+      memset(c->ws, 0, sizeof c->ws);
+      memset(c->cap, 0, sizeof c->cap);
+      c->fixed_ws = true;
+      c->fixed_used = 0;
+    }
+    ~swap_ws() {
+      memcpy(c->ws, ws, sizeof ws);
+      memcpy(c->cap, cap, sizeof cap);
+      c->fixed_ws = false;
+    }
+  } guard(ctx);
+  hostg1::Pt r;
+  rc = msm_core(ctx, b, off, 1, n, (const uint8_t*)d_scalars_be, &r);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);  // nothing of a failed call may still run on the shared array
+    return rc;
+  }
   hostg1::marshal(out_xy_be, r);
   return BN256_OK;
 }

@@ -145,6 +145,13 @@ class Engine:
         self._chk(self.lib.bn256_msm_dev(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), out))
         return out.raw
 
+    def msm_dev_noalloc(self, bases: Bases, dev_ptr: int, n: int, off: int = 0) -> bytes:
+        """msm_dev with every workspace in the library's static device array: no hipMalloc / hipFree
+        (include/bn256msm.h: bn256_msm_dev_noalloc; BN256_ESCRATCH above its size limit)."""
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm_dev_noalloc(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), out))
+        return out.raw
+
     def msm_submit(self, bases: Bases, dev_ptr: int, n: int, off: int = 0) -> int:
         """Enqueues msm_dev on a free lane and returns its ticket (include/bn256msm.h: bn256_msm_submit)."""
         t = C.c_int(-1)

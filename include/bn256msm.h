@@ -37,6 +37,7 @@ typedef struct bn256_bases bn256_bases;
 #define BN256_ENOMEM (-6)
 #define BN256_ETOOLARGE (-7)   /* n * windows exceeds 2^31 entries */
 #define BN256_EBUSY (-8)       /* bn256_msm_submit: every lane holds a submitted call */
+#define BN256_ESCRATCH (-9)    /* bn256_msm_dev_noalloc: the call does not fit the static scratch array */
 
 /* bn256_bases_upload flags */
 #define BN256_PRECOMPUTE 1 /* also store 2^(c*w) * P for every window w (fixed-base MSM) */
@@ -62,6 +63,28 @@ int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const 
               uint8_t out_xy_be[64]);
 int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                   uint8_t out_xy_be[64]);
+
+/* Device inputs of every *_dev / *_submit / *_noalloc call: `d_scalars_be` must be 16-byte aligned (the
+ * kernels read scalars with 128-bit loads), and the kernels run on the library's own non-blocking
+ * streams (bn256_ctx_stream and one per lane), which do not wait for any other stream: when another
+ * stream produced the scalars (torch's current stream, say), the caller synchronises that stream or
+ * event before the call. */
+
+/* bn256_msm_dev for callers that cannot call hipMalloc: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation.  It has NO counterpart in the reference (whose
+ * vectorPointScalarMul, go/bp/util.go:165-175, allocates freely on the Go heap); same arguments, same
+ * result bytes as bn256_msm_dev.  The call makes no hipMalloc / hipFree / hipHostMalloc and no other
+ * allocating library call: the pipeline's workspaces (sort records, bucket offsets, bucket and partial
+ * sums, packed results) are carved from a file-scope __device__ array of BN256_NOALLOC_SCRATCH_BYTES
+ * that every GPU the library runs on holds until the process ends; its device address is resolved once
+ * per device by bn256_ctx_create.  A call whose workspaces do not fit returns BN256_ESCRATCH before
+ * anything is enqueued: 256 MiB hold a fixed-base (BN256_PRECOMPUTE) call of up to 2^20 points and a
+ * table-less call of up to 2^18.  All contexts on one GPU share that GPU's array and it keeps the last
+ * call's contents (the pipeline initialises what it reads): calls that overlap on one GPU -- two
+ * contexts, two threads -- race; serialise them.  The other entry points are unaffected. */
+#define BN256_NOALLOC_SCRATCH_BYTES ((size_t)256 << 20)
+int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
+                          uint8_t out_xy_be[64]);
 
 /* bn256_msm_dev split in two, for callers with several independent commitments to make -- A and S
  * (go/bp/main.go:89,95), L and R of an inner-product level (go/bp/main.go:340-341), the WNLA
