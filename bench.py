@@ -2,27 +2,40 @@
 """Headline benchmark: BN256 G1 multi-scalar multiplication (the reference's
 vectorPointScalarMul, go/bp/util.go:165-175) on MI355X.
 
-  python bench.py [--gpus N --steps K --warmup W] [--log2n 20]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N --steps K --warmup W] [--log2n 20 | --total-log2n 24]
 
-A "step" is one complete MSM: every rank runs the device pipeline on its contiguous slice of
-2^log2n points (bases resident in HBM with their fixed-base table, scalars resident in HBM
-when the timed region starts), the 64-byte partial sums are exchanged with one RCCL
-all_gather, and every rank adds them on the host.  value = total points / second.
-Steps are issued through bn256_msm_submit / bn256_msm_wait with --depth (default 3) calls in
-flight, the way a prover issues its independent commitments (A and S, L and R): step i+1 is
-enqueued before step i's result is collected, and all K results are collected inside the timed
-region.  --depth 1 is the strictly blocking sequence; its rate is also reported
-("blocking_call", measured after the timed region).
-Weak scaling: the per-GPU slice is fixed (2^20 by default = BASELINE.json configs[2]); with
---log2n 21 --gpus 8 the job is exactly configs[4] (2^24 points over 8 GPUs).
+`python bench.py --gpus N` with N > 1 works as a bare command: when WORLD_SIZE is unset the process
+that was started is only a launcher -- it makes no GPU call, starts N fresh ranks of this script
+(crypto_amd/launch.py: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), waits and
+relays rank 0's single JSON line.  Under `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N` the ranks are the launcher's and this script is a rank at once.
+
+A "step" is one complete MSM: every rank runs the device pipeline on its contiguous slice of the
+points (bases resident in HBM with their fixed-base table, scalars resident in HBM when the timed
+region starts), the 64-byte partial sums are exchanged with one RCCL all_gather, and every rank adds
+them on the host.  value = total points / second.  Steps are issued through bn256_msm_submit /
+bn256_msm_wait with --depth (default 3) calls in flight, the way a prover issues its independent
+commitments (A and S, L and R): step i+1 is enqueued before step i's result is collected, and all K
+results are collected inside the timed region.
+
+  default            weak scaling: 2^log2n points per GPU (2^20 = BASELINE.json configs[2] per GPU)
+  --total-log2n T    strong scaling: 2^T points in all, rank r takes the r-th contiguous slice
+                     (--gpus 8 --total-log2n 24 is configs[4]; --gpus 1 --total-log2n 24 the same job
+                     on one GPU, in eight passes)
+
+Besides `value` the line carries, measured in the same run: `single_call` (SURVEY 8d's wording of
+the metric: one blocking call, median), `pcie_inclusive` (scalars in host memory, never `value`),
+`bulletproofs_like` (the aL / aR scalar distribution), `n_2p24` (2^24 points on this one GPU) at
+N = 1, and `strong_2p24` (2^24 points over all ranks) at N > 1.
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for the roofline accounting.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,6 +45,24 @@ sys.path.insert(0, ROOT)
 IMAD_PER_POINT = 23120          # 17 windows x 10 modmul x 136 IMAD
 IMAD_PEAK = 3.47e13             # measured v_mad_u64_u32 lane-ops/s, profiles/r01_ubench_valu.txt
 SEED_BASES, SEED_SCALARS = 0x5EED0001, 0x5EED0002
+N_ORDER = 0x8FB501E34AA387F9AA6FECB86184DC212E8D8E12F82B39241A2EF45B57AC7261
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log2n", type=int, default=20, help="weak scaling: points per GPU = 2^log2n")
+    ap.add_argument("--total-log2n", type=int, default=0, help="strong scaling: 2^T points over all GPUs")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-precompute", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip single_call / pcie / 2^24 / bulletproofs-like legs")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 17)
+    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3], help="MSM calls in flight per GPU")
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(sample_terms: int):
@@ -42,25 +73,24 @@ def cpu_baseline(sample_terms: int):
     bases = orc.synth_bases(SEED_BASES, sample_terms)
     scalars = orc.synth_scalars(SEED_SCALARS, sample_terms)
     t0 = time.perf_counter()
-    out = orc.msm(bases, scalars, mt=False)
+    orc.msm(bases, scalars, mt=False)
     dt = time.perf_counter() - t0
-    return sample_terms / dt, out, orc
+    return sample_terms / dt, orc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
-    ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--no-precompute", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3], help="MSM calls in flight per GPU")
-    args = ap.parse_args()
+def launcher(args) -> int:
+    """The bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE): no GPU call here, N fresh ranks."""
+    from crypto_amd import launch
+    script = os.environ.get("BENCH_CHILD_SCRIPT") or os.path.abspath(__file__)  # override: CPU test of this path
+    return launch.launch_ranks(script, sys.argv[1:], args.gpus)
 
+
+def worker(args) -> int:
+    # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version
+    # banner at communicator set-up, gloo's connection notice) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -68,8 +98,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # BENCH_FORCE_DIST=1 runs the multi-GPU code path (process group, all_gather of partials, barrier)
@@ -84,114 +113,165 @@ def main():
     from crypto_amd import sharding
     eng = crypto_amd.Engine(local_rank)
     eng.set_tuning(args.window_bits, args.chunk)
-    n = 1 << args.log2n
-    first = rank * n
     flags = 0 if args.no_precompute else crypto_amd.PRECOMPUTE
-    t0 = time.perf_counter()
-    bases = eng.random_bases(SEED_BASES, n, first=first, flags=flags)
-    setup_s = time.perf_counter() - t0
-    scalars = torch.empty(n * 32, dtype=torch.uint8, device=dev)
-    eng.random_scalars_into(SEED_SCALARS, n, scalars.data_ptr(), first=first)
-
     ex = sharding.AsyncExchange(world, dev) if use_dist else None
     host_us = [0.0] * 3  # host time in submit / wait / exchange (start, finish of an older one, sum)
-
-    def run(steps, depth, phase=None):
-        def wait(ticket):
-            p = eng.msm_wait(ticket)
-            if phase is not None:
-                phase[:] = [a + b for a, b in zip(phase, eng.last_timing())]
-            return p
-
-        return sharding.run_pipelined(steps, depth, lambda: eng.msm_submit(bases, scalars.data_ptr(), n), wait, ex, host_us)
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.depth, args.depth)  # set-up: every lane allocates its workspaces
-    result = run(args.warmup, args.depth)
-    sync()
+    class Workload:
+        """This rank's slice [first, first + n) of a job of n_total synthetic points, resident in HBM."""
+
+        def __init__(self, n_total, strong):
+            self.n_total, self.strong = n_total, strong
+            self.first, self.n = sharding.split_even(n_total, world, rank) if strong else (rank * (n_total // world), n_total // world)
+            t0 = time.perf_counter()
+            self.bases = eng.random_bases(SEED_BASES, self.n, first=self.first, flags=flags)
+            self.setup_s = time.perf_counter() - t0
+            self.scalars = torch.empty(max(self.n, 1) * 32, dtype=torch.uint8, device=dev)
+            eng.random_scalars_into(SEED_SCALARS, self.n, self.scalars.data_ptr(), first=self.first)
+
+        def run(self, steps, depth, phase=None):
+            def submit():
+                return eng.msm_submit(self.bases, self.scalars.data_ptr(), self.n)
+
+            def wait(ticket):
+                p = eng.msm_wait(ticket)
+                if phase is not None:
+                    phase[:] = [a + b for a, b in zip(phase, eng.last_timing())]
+                return p
+
+            return sharding.run_pipelined(steps, depth, submit, wait, ex, host_us)
+
+        def blocking_calls(self, calls, phase=None):
+            """`calls` strictly blocking steps (MSM, exchange, host sum), each timed on the host."""
+            ts, res = [], None
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                res = self.run(1, 1, phase)
+                ts.append(time.perf_counter() - t0)
+            return ts, res
+
+        def timed(self, steps, depth):
+            """barrier + synchronize on both sides, MAX over ranks; returns (seconds, last result)."""
+            sync()
+            t0 = time.perf_counter()
+            res = self.run(steps, depth)
+            sync()
+            dt = time.perf_counter() - t0
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item()), res
+
+        def free(self):
+            self.bases.free()
+            self.scalars = None
+
+    strong = args.total_log2n > 0
+    n_total = (1 << args.total_log2n) if strong else (1 << args.log2n) * world
+    wl = Workload(n_total, strong)
+    n = wl.n
+    # set-up (untimed, before the W warm-up steps): every lane allocates its workspaces; with an exchange,
+    # enough steps for RCCL to finish its lazy channel set-up (the first collectives take milliseconds)
+    wl.run(args.depth + (8 if use_dist else 0), args.depth)
+    wl.run(args.warmup, args.depth)
     host_us[:] = [0.0] * 3
-    t0 = time.perf_counter()
-    result = run(args.steps, args.depth)
-    sync()
-    dt = time.perf_counter() - t0
-    host_timed = [x / max(args.steps, 1) for x in host_us]
+    dt, result = wl.timed(args.steps, args.depth)
+    steps = max(args.steps, 1)
+    host_timed = [x / steps for x in host_us]
     # The same K steps as strictly blocking calls (not part of `value`).  The per-phase HIP events and
     # the roofline's kernel time are taken here: with several calls in flight an event pair also spans
     # the time a kernel waits behind the other call's kernels, which is not kernel time.
     phase = [0.0] * 7
-    t0 = time.perf_counter()
-    result_blocking = run(args.steps, 1, phase)
+    nblk = max(args.steps, 10)
+    wl.run(2, 1)
     sync()
-    dt_blocking = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    per_call, result_blocking = wl.blocking_calls(nblk, phase)
+    sync()
+    dt_blocking = sum(per_call)
 
+    line = None
     if rank == 0:
-        steps = max(args.steps, 1)
-        traffic = executed = None
-        try:  # HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (2^20, c=16 only)
-            if args.log2n == 20 and not args.no_precompute and not args.window_bits:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_2p20.json")) as f:
+        traffic = executed = pmc_file = None
+        try:  # HBM bytes per k_accumulate launch from the committed rocprofv3 PMC passes (2^20, default tuning only)
+            if n == (1 << 20) and not args.no_precompute and not args.window_bits:
+                pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_2p20.json")))[-1]
+                with open(pmc_file) as f:
                     pmc = json.load(f)["k_accumulate"]
                 traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
                 # executed work next to the canonical 23 120 IMAD/point (SURVEY 8d: "report executed
                 # IMADs so waste is visible"): VALU lane-operations of all kinds per point
                 executed = pmc["SQ_INSTS_VALU"] * 64.0 / n
         except Exception:
-            traffic = executed = None
-        phase = [p / steps for p in phase]
+            traffic = executed = pmc_file = None
+        phase = [p / nblk for p in phase]
         acc_s = phase[3] * 1e-3
-        achieved = n * IMAD_PER_POINT / acc_s if acc_s > 0 else 0.0
+        # a fixed-base call above 2^21 points runs as passes of 2^21 (MSM_CHUNK in bn256msm.hip), one
+        # k_accumulate launch each; a submitted call reports the phase times of its last pass
+        n_launch = min(n, 1 << 21) if not args.no_precompute else n
+        if n > n_launch and n % n_launch:
+            n_launch = n % n_launch
+        achieved = n_launch * IMAD_PER_POINT / acc_s if acc_s > 0 else 0.0
+        med = statistics.median(per_call) if per_call else float("nan")
         line = {
             "metric": "MSM points/sec (BN256 G1, bit-exact with the reference's normalised affine output)",
-            "value": n * world * args.steps / dt,
+            "value": n_total * args.steps / dt,
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "int32x9 (29-bit digits, v_mad_i64_i32)",
             "data": "synthetic (seeded k_i*G0 bases, uniform scalars mod n)",
             "config": {
-                "workload": f"single BN256 G1 MSM, 2^{args.log2n} points per GPU x {world} GPU(s) "
-                            f"(BASELINE.json configs[2] at log2n=20; configs[4] at log2n=21, 8 GPUs)",
+                "workload": (f"single BN256 G1 MSM, 2^{args.total_log2n} points in all, sliced over {world} GPU(s) "
+                             f"(BASELINE.json configs[4] at T=24, 8 GPUs)" if strong else
+                             f"single BN256 G1 MSM, 2^{args.log2n} points per GPU x {world} GPU(s) "
+                             f"(BASELINE.json configs[2] per GPU at log2n=20)"),
+                "points_total": n_total,
                 "points_per_gpu": n,
+                "rank0_slice": [wl.first, wl.n],
                 "fixed_base_table": not args.no_precompute,
-                "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials",
+                "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials, host sum",
                 "calls_in_flight": args.depth,
-                "setup_seconds_bases": setup_s,
+                "setup_seconds_bases": wl.setup_s,
                 "result_xy": result.hex(),
             },
-            # per call, HIP events on the call's stream, over the K blocking calls that follow the timed region
+            # per call, HIP events on the call's stream, over the blocking calls that follow the timed region
             "phases_ms": {"sort_pass_a": phase[0], "scan": phase[1], "sort_pass_b": phase[2], "accumulate": phase[3],
                           "fix": phase[4], "reduce": phase[5], "device_total": phase[6]},
             "host_us_per_step": {"submit": host_timed[0], "wait": host_timed[1], "exchange": host_timed[2]},
-            "blocking_call": {"ms_per_call": dt_blocking / steps * 1e3, "points_per_s": n * world * args.steps / dt_blocking,
-                              "same_result": bool(result_blocking == result)},
+            # SURVEY 8(d)'s wording of the metric: N / wall time of ONE blocking call (result download and,
+            # at N > 1, exchange included; scalars resident), median of >= 10 after 2 warm-ups
+            "single_call": {"calls": nblk, "median_ms": med * 1e3, "mean_ms": dt_blocking / nblk * 1e3,
+                            "points_per_s": n_total / med if med == med else None,
+                            "whole_msm_frac": (n * IMAD_PER_POINT / med) / IMAD_PEAK if med == med else None,
+                            "same_result": bool(result_blocking == result)},
             "roofline": {
                 "bound": "valu_int",
                 "kernel": "k_accumulate",
                 "kernel_ms": phase[3],
-                "measured_over": f"{args.steps} blocking calls after the timed region (one call on the chip at a time)",
+                "points_per_launch": n_launch,
+                "measured_over": f"{nblk} blocking calls after the timed region (one call on the chip at a time), "
+                                 f"HIP events on the call's own stream",
                 "achieved": achieved,
                 "peak": IMAD_PEAK,
                 "unit": "IMAD/s",
                 "frac": achieved / IMAD_PEAK,
                 "traffic": traffic,
+                "traffic_source": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
                 "executed_valu_lane_ops_per_point": executed,
                 "whole_msm_frac": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK,
             },
         }
-        if not args.no_precompute and n >= (1 << 18):
+        if not args.no_precompute and n >= (1 << 18) and n <= (1 << 21) and not args.window_bits:
             # HBM rate of the sort / scatter phases (two-pass sort, 16 windows): ALGORITHMIC bytes -- 32-byte
             # scalars in, one 4-byte record per (point, window) out, then records in, sorted entries out --
             # over the live phase times; the PMC counters are in profiles/ and DESIGN.md 6
@@ -201,21 +281,106 @@ def main():
                 "pass_b": {"bytes": 2 * ent, "ms": phase[2], "GB/s": 2 * ent / (phase[2] * 1e-3) / 1e9},
                 "peak_GB/s": 8000.0,
             }
-        if world == 1 and not args.no_cpu_baseline:
-            v, _, orc = cpu_baseline(args.cpu_sample)
-            # the oracle as checker: exact answer of the whole timed workload from its closed form
-            # (bases are k_i*G0 with known k_i), bit-for-bit against the device result
-            exact = orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, n)
-            line["cpu_baseline"] = {
-                "value": v, "unit": "points/s", "cores": 1, "kind": "port",
-                "device_result_matches_oracle_closed_form": bool(exact == result),
-                "sample": f"first {args.cpu_sample} terms of the same seeded workload, reference algorithm "
-                          f"(per-term double-and-add + add, go/bp/util.go:165-175) restated in C, 1 thread",
-            }
-        print(json.dumps(line), flush=True)
+
+    orc = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        v, orc = cpu_baseline(args.cpu_sample)
+        # the oracle as checker: exact answer of the whole timed workload from its closed form
+        # (bases are k_i*G0 with known k_i), bit-for-bit against the device result
+        exact = orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, n_total)
+        line["cpu_baseline"] = {
+            "value": v, "unit": "points/s", "cores": 1, "kind": "port",
+            "device_result_matches_oracle_closed_form": bool(exact == result),
+            "sample": f"first {args.cpu_sample} terms of the same seeded workload, reference algorithm "
+                      f"(per-term double-and-add + add, go/bp/util.go:165-175) restated in C, 1 thread",
+        }
+
+    if not args.no_extras and not strong and not args.no_precompute:
+        if world == 1:
+            line.update(extras_one_gpu(eng, wl, orc, dev, torch))
+        # 2^24 points in all (configs[4]'s job): on this GPU at N = 1, sliced over the ranks at N > 1
+        wl.free()
+        big = Workload(1 << 24, True)
+        big.run(2, args.depth)
+        ksteps = 6
+        dtb, resb = big.timed(ksteps, args.depth)
+        big.run(2, 1)
+        sync()
+        calls, _ = big.blocking_calls(5)
+        sync()
+        if rank == 0:
+            entry = {"points_total": 1 << 24, "points_per_gpu": big.n, "scaling": "strong",
+                     "steps": ksteps, "calls_in_flight": args.depth,
+                     "ms_per_step": dtb / ksteps * 1e3, "points_per_s": (1 << 24) * ksteps / dtb,
+                     "single_call_median_ms": statistics.median(calls) * 1e3,
+                     "single_call_points_per_s": (1 << 24) / statistics.median(calls),
+                     "whole_msm_frac": (big.n * IMAD_PER_POINT / (dtb / ksteps)) / IMAD_PEAK,
+                     "setup_seconds_bases": big.setup_s, "result_xy": resb.hex()}
+            if orc is not None:
+                entry["matches_oracle_closed_form"] = bool(orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, 1 << 24) == resb)
+            line["n_2p24" if world == 1 else "strong_2p24"] = entry
+        big.free()
+
+    if rank == 0:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if use_dist:
         dist.destroy_process_group()
     eng.close()
+    return 0
+
+
+def extras_one_gpu(eng, wl, orc, dev, torch) -> dict:
+    """N = 1 legs that are not `value`: scalars in host memory, Bulletproofs-like scalars."""
+    import numpy as np
+    n = wl.n
+    out = {}
+
+    def med_of(fn, reps=10, warm=2):
+        for _ in range(warm):
+            r = fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), r
+
+    want = eng.msm_dev(wl.bases, wl.scalars.data_ptr(), n)
+    # SURVEY 8(d): wall time of bn256_msm with the scalar upload and the result download included
+    host = wl.scalars.cpu()
+    pageable = host.numpy()
+    pinned = host.pin_memory()
+    t_pg, r_pg = med_of(lambda: eng.msm_host_ptr(wl.bases, pageable.ctypes.data, n))
+    t_pin, r_pin = med_of(lambda: eng.msm_host_ptr(wl.bases, pinned.data_ptr(), n))
+    out["pcie_inclusive"] = {
+        "note": "bn256_msm: 32 B/point of scalars cross PCIe inside the call; never `value`",
+        "pageable": {"median_ms": t_pg * 1e3, "points_per_s": n / t_pg, "same_result": bool(r_pg == want)},
+        "pinned": {"median_ms": t_pin * 1e3, "points_per_s": n / t_pin, "same_result": bool(r_pin == want)},
+    }
+    # Bulletproofs-like (go/bp/main.go:84-85): aL bits in {0,1} over the first half, aR = aL - 1 in
+    # {0, n-1} over the second
+    rng = np.random.default_rng(7)
+    bits = rng.integers(0, 2, size=n // 2, dtype=np.uint8)
+    arr = np.zeros((n, 32), dtype=np.uint8)
+    arr[: n // 2, 31] = bits
+    arr[n // 2:][bits == 0] = np.frombuffer((N_ORDER - 1).to_bytes(32, "big"), dtype=np.uint8)
+    dbp = torch.from_numpy(arr.reshape(-1)).to(dev)
+    torch.cuda.synchronize()
+    t_bp, r_bp = med_of(lambda: eng.msm_dev(wl.bases, dbp.data_ptr(), n))
+    out["bulletproofs_like"] = {"median_ms": t_bp * 1e3, "points_per_s": n / t_bp,
+                                "distribution": "first half uniform in {0,1}, second half = first - 1 mod n (aL, aR of go/bp/main.go:84-85)"}
+    if orc is not None:
+        out["bulletproofs_like"]["matches_oracle_closed_form"] = bool(
+            orc.synth_msm_closed_form_scalars(SEED_BASES, arr.tobytes()) == r_bp)
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launcher(args))
+    sys.exit(worker(args))
 
 
 if __name__ == "__main__":

@@ -140,6 +140,12 @@ class Engine:
         self._chk(self.lib.bn256_msm(self.ctx, bases.h, off, n, bytes(raw), out))
         return out.raw
 
+    def msm_host_ptr(self, bases: Bases, host_ptr: int, n: int, off: int = 0) -> bytes:
+        """bn256_msm with the scalars at a host address (pageable or pinned): the upload is part of the call."""
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bn256_msm(self.ctx, bases.h, off, n, C.cast(C.c_void_p(host_ptr), C.c_char_p), out))
+        return out.raw
+
     def msm_dev(self, bases: Bases, dev_ptr: int, n: int, off: int = 0) -> bytes:
         out = C.create_string_buffer(64)
         self._chk(self.lib.bn256_msm_dev(self.ctx, bases.h, off, n, C.c_void_p(dev_ptr), out))

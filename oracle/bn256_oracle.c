@@ -326,6 +326,38 @@ void orc_synth_dot(uint8_t out_be[32], uint64_t seed_b, uint64_t seed_s, size_t 
     le_to_be32(out_be, acc);
 }
 
+/* out_be = sum_{i<n} a_i * b_i mod n for two vectors of 32-byte big-endian scalars (values >= n are
+ * reduced first): vectorMul, go/bp/util.go:132-142.  With b_i = the synthetic base scalars k_i this is
+ * the closed form of an MSM over the synthetic bases for ANY scalar vector a. */
+static void be32_to_le_mod_n(uint64_t v[4], const uint8_t *b) {
+    for (int i = 0; i < 4; i++) {
+        v[i] = 0;
+        for (int k = 0; k < 8; k++) v[i] = (v[i] << 8) | b[(3 - i) * 8 + k];
+    }
+    if (geq(v, N_.l)) sub4(v, v, N_.l);
+}
+void orc_fr_dot(uint8_t out_be[32], const uint8_t *a_be, const uint8_t *b_be, size_t n) {
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        uint64_t a[4], b[4], ar[4], pr[4];
+        be32_to_le_mod_n(a, a_be + 32 * i);
+        be32_to_le_mod_n(b, b_be + 32 * i);
+        fr_mont(ar, a, NR2_);
+        fr_mont(pr, ar, b);
+        if (add4(acc, acc, pr) || geq(acc, N_.l)) sub4(acc, acc, N_.l);
+    }
+    le_to_be32(out_be, acc);
+}
+/* the synthetic base scalars k_i themselves (0 -> 1), 32-byte big-endian: base_i = k_i * G0 */
+void orc_synth_base_scalars(uint8_t *out_be, uint64_t seed, size_t first, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        uint64_t v[4];
+        synth_scalar_le(v, seed, first + i);
+        if ((v[0] | v[1] | v[2] | v[3]) == 0) v[0] = 1;
+        le_to_be32(out_be + 32 * i, v);
+    }
+}
+
 /* Keccak-256, legacy 0x01 padding (iden3 keccak256.Hash, go/bp/util.go:232). */
 static const uint64_t KRC[24] = {
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,

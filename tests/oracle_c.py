@@ -30,6 +30,10 @@ class OracleC:
         L.orc_synth_bases_mt.restype = None
         L.orc_synth_dot.argtypes = [cp, C.c_uint64, C.c_uint64, sz, sz]
         L.orc_synth_dot.restype = None
+        L.orc_fr_dot.argtypes = [cp, cp, cp, sz]
+        L.orc_fr_dot.restype = None
+        L.orc_synth_base_scalars.argtypes = [cp, C.c_uint64, sz, sz]
+        L.orc_synth_base_scalars.restype = None
         L.orc_keccak256.argtypes = [cp, cp, sz]
         L.orc_keccak256.restype = None
 
@@ -48,6 +52,32 @@ class OracleC:
         out = C.create_string_buffer(32)
         self.L.orc_synth_dot(out, seed_b, seed_s, first, n)
         return int.from_bytes(out.raw, "big")
+
+    def fr_dot(self, a_be: bytes, b_be: bytes) -> int:
+        """vectorMul (go/bp/util.go:132-142) of two marshalled scalar vectors of equal length."""
+        assert len(a_be) == len(b_be) and len(a_be) % 32 == 0
+        out = C.create_string_buffer(32)
+        self.L.orc_fr_dot(out, a_be, b_be, len(a_be) // 32)
+        return int.from_bytes(out.raw, "big")
+
+    def synth_base_scalars(self, seed, n, first=0) -> bytes:
+        """k_i of the synthetic bases k_i*G0 (32-byte big-endian each)."""
+        buf = C.create_string_buffer(32 * max(n, 1))
+        self.L.orc_synth_base_scalars(buf, seed, first, n)
+        return buf.raw[:32 * n]
+
+    def g0_mul(self, k: int) -> bytes:
+        g0 = (1).to_bytes(32, "big") + (0x8fb501e34aa387f9aa6fecb86184dc21ee5b88d120b5b59e185cac6c5e089667 - 2).to_bytes(32, "big")
+        out = C.create_string_buffer(64)
+        rc = self.L.orc_g1_scalar_mult(out, g0, (k % 0x8fb501e34aa387f9aa6fecb86184dc212e8d8e12f82b39241a2ef45b57ac7261).to_bytes(32, "big"))
+        if rc:
+            raise ValueError(f"oracle rc {rc}")
+        return out.raw
+
+    def synth_msm_closed_form_scalars(self, seed_b, scalars_be: bytes, first=0) -> bytes:
+        """(sum_i a_i*k_i mod n)*G0: the exact MSM of ANY scalar vector over the synthetic bases."""
+        n = len(scalars_be) // 32
+        return self.g0_mul(self.fr_dot(scalars_be, self.synth_base_scalars(seed_b, n, first)))
 
     def synth_msm_closed_form(self, seed_b, seed_s, n, first=0) -> bytes:
         """The synthetic MSM's exact answer without the per-term loop: the bases are k_i*G0 with

@@ -77,6 +77,31 @@ def test_two_rank_sharded_msm_matches_single():
     assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 151, 151, 150)
 
 
+def test_bench_launcher_parent_to_children_to_one_json_line():
+    """`python bench.py --gpus 2` as a bare command: the parent (no WORLD_SIZE) starts two fresh ranks,
+    relays rank 0's single JSON line and propagates a failing rank's exit code.  The ranks here are
+    tests/_bench_child_cpu.py (gloo + the oracle: this tier has no GPU); everything in the parent is
+    bench.py's own code path."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_c import OracleC
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_CHILD_SCRIPT"] = os.path.join(ROOT, "tests", "_bench_child_cpu.py")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--warmup", "1", "--total-log2n", "8"]
+    r = subprocess.run(cmd + ["--steps", "4"], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    orc = OracleC()
+    want = orc.msm(orc.synth_bases(0x5EED0001, 256), orc.synth_scalars(0x5EED0002, 256))
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["result_xy"] == want.hex()
+    # a failing rank: non-zero exit, no JSON line, the other rank is not left behind in a collective
+    r = subprocess.run(cmd + ["--steps", "13"], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 7 and not r.stdout.strip(), (r.returncode, r.stdout)
+
+
 def test_run_pipelined_schedule():
     """sharding.run_pipelined (the loop bench.py times) with stand-ins for the device and the exchange:
     every step's result is collected and exchanged exactly once, in order; never more than `depth`
