@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BN256MSM_LIB") or os.path.join(_HERE, "libbn256msm.so")  # override: A/B builds
 
 EXPORTS = [
-    "bn256_ctx_create", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
+    "bn256_ctx_create", "bn256_ctx_create_multi", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
     "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_dev_noalloc", "bn256_msm_submit", "bn256_msm_wait", "bn256_msm_multi", "bn256_msm_multi_strided", "bn256_fold2", "bn256_scalar_mul_batch",
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
@@ -39,6 +39,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     vp, sz, u8p, i = C.c_void_p, C.c_size_t, C.c_char_p, C.c_int
     lib.bn256_ctx_create.argtypes = [i, C.POINTER(vp)]
+    lib.bn256_ctx_create_multi.argtypes = [C.POINTER(C.c_int), i, C.POINTER(vp)]
     lib.bn256_ctx_destroy.argtypes = [vp]
     lib.bn256_ctx_destroy.restype = None
     lib.bn256_ctx_stream.argtypes = [vp]

@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/bn256msm.h"
@@ -138,6 +139,11 @@ struct bn256_bases {
   int c;          // window bits the levels were built for (0 when levels == 1)
   size_t cap;     // bytes of the block behind d (pool)
   int dev;
+  // handle of a multi-device context (bn256_ctx_create_multi): d == nullptr, shard s holds the
+  // contiguous slice [shard_off[s], shard_off[s + 1]) as an ordinary handle on its device
+  int nshard;
+  bn256_bases* shard[BN256_MAX_DEVICES];
+  size_t shard_off[BN256_MAX_DEVICES + 1];
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
@@ -167,7 +173,29 @@ struct bn256_ctx {
   // pinned result buffer) on the same device, created on first use
   bn256_ctx* lane[BN256_ASYNC_LANES];
   struct msm_pending* pending[BN256_ASYNC_LANES];
+  // bn256_ctx_create_multi: this context is only the parent of nshard ordinary contexts, one per
+  // entry of the device list (it has no stream or workspace of its own)
+  int nshard;
+  bn256_ctx* shard[BN256_MAX_DEVICES];
 };
+
+// entry points that a multi-device context serves on its first device (Fr vectors, synthetic scalars,
+// the self test) and those it does not serve at all
+#define PRIMARY_SHARD(ctx)                                   \
+  do {                                                       \
+    if ((ctx) && (ctx)->nshard) (ctx) = (ctx)->shard[0];     \
+  } while (0)
+#define SINGLE_DEVICE_ONLY(ctx)                              \
+  do {                                                       \
+    if ((ctx) && (ctx)->nshard) return BN256_ENOTSUP;        \
+  } while (0)
+// multi-device paths (end of this file)
+static int multi_bases_make(bn256_ctx* ctx, const uint8_t* xy_be, bool synth, uint64_t seed, size_t first, size_t n,
+                            int flags, bn256_bases** out);
+static void multi_bases_free(bn256_ctx* ctx, bn256_bases* b);
+static int multi_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be);
+static int multi_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars, bool on_device,
+                     uint8_t out_xy_be[64]);
 
 static int ws_reserve(bn256_ctx* ctx, int which, size_t bytes) {
   if (ctx->cap[which] >= bytes) return BN256_OK;
@@ -208,6 +236,7 @@ extern "C" const char* bn256_strerror(int code) {
     case BN256_ENOMEM: return "out of device memory";
     case BN256_ETOOLARGE: return "problem too large (n * windows >= 2^31)";
     case BN256_EBUSY: return "every asynchronous lane holds a submitted call: wait for one first";
+    case BN256_ENOTSUP: return "not supported on a multi-device context / sharded handle (see bn256_ctx_create_multi)";
     case BN256_ESCRATCH: return "bn256_msm_dev_noalloc: the call needs more workspace than the static scratch array holds (BN256_NOALLOC_SCRATCH_BYTES)";
     default: return "unknown error";
   }
@@ -217,6 +246,11 @@ extern "C" const char* bn256_strerror(int code) {
 // failure path of bn256_ctx_create, so that a half-built context is not leaked.
 static void pending_free(struct msm_pending* p);
 static void ctx_teardown(bn256_ctx* ctx, bool counted) {
+  if (ctx->nshard) {  // a multi-device parent owns nothing but its shards
+    for (int s = 0; s < ctx->nshard; s++) bn256_ctx_destroy(ctx->shard[s]);
+    delete ctx;
+    return;
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < BN256_ASYNC_LANES; i++) {
@@ -285,12 +319,40 @@ extern "C" void bn256_ctx_destroy(bn256_ctx* ctx) {
   ctx_teardown(ctx, true);
 }
 
-extern "C" void* bn256_ctx_stream(bn256_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int bn256_ctx_create_multi(const int* devices, int ndev, bn256_ctx** out) {
+  if (!out) return BN256_EINVAL;
+  *out = nullptr;
+  if (!devices || ndev < 1 || ndev > BN256_MAX_DEVICES) return BN256_EINVAL;
+  bn256_ctx* ctx = new (std::nothrow) bn256_ctx();
+  if (!ctx) return BN256_ENOMEM;
+  memset(ctx, 0, sizeof *ctx);
+  ctx->device = devices[0];
+  for (int s = 0; s < ndev; s++) {
+    int rc = bn256_ctx_create(devices[s], &ctx->shard[s]);
+    if (rc) {
+      ctx->nshard = s;  // destroy what exists
+      if (s == 0) delete ctx; else ctx_teardown(ctx, false);
+      return rc;
+    }
+  }
+  ctx->nshard = ndev;
+  *out = ctx;
+  return BN256_OK;
+}
+
+extern "C" void* bn256_ctx_stream(bn256_ctx* ctx) {
+  PRIMARY_SHARD(ctx);
+  return ctx ? (void*)ctx->stream : nullptr;
+}
 
 extern "C" int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk) {
   if (!ctx) return BN256_EINVAL;
   if (window_bits != 0 && (window_bits < 2 || window_bits > 22)) return BN256_EINVAL;
   if (chunk < 0 || chunk > 65536) return BN256_EINVAL;
+  for (int s = 0; s < ctx->nshard; s++) {
+    ctx->shard[s]->tune_c = window_bits;
+    ctx->shard[s]->tune_k = chunk;
+  }
   ctx->tune_c = window_bits;
   ctx->tune_k = chunk;
   return BN256_OK;
@@ -299,6 +361,13 @@ extern "C" int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk) 
 extern "C" int bn256_last_timing(bn256_ctx* ctx, float* ms, int cap) {
   if (!ctx || !ms) return 0;
   int k = std::min(cap, 7);
+  if (ctx->nshard) {  // the shards run side by side: the slowest one
+    for (int i = 0; i < k; i++) {
+      ms[i] = 0.f;
+      for (int sh = 0; sh < ctx->nshard; sh++) ms[i] = std::max(ms[i], ctx->shard[sh]->last_ms[i]);
+    }
+    return k;
+  }
   for (int i = 0; i < k; i++) ms[i] = ctx->last_ms[i];
   return k;
 }
@@ -375,6 +444,7 @@ extern "C" int bn256_bases_upload(bn256_ctx* ctx, const uint8_t* xy_be, size_t n
   if (!ctx || !out || (!xy_be && n)) return BN256_EINVAL;
   *out = nullptr;
   if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  if (ctx->nshard) return multi_bases_make(ctx, xy_be, false, 0, 0, n, flags, out);
   HIPCHK(hipSetDevice(ctx->device));
   bool precomp = (flags & BN256_PRECOMPUTE) != 0 && n > 0;
   int c = precomp ? pick_c(ctx, n, true) : 0;
@@ -417,6 +487,8 @@ static void wait_for_submitted(bn256_ctx* ctx) {
 
 extern "C" void bn256_bases_free(bn256_ctx* ctx, bn256_bases* b) {
   if (!b) return;
+  if (b->nshard) return multi_bases_free(ctx, b);
+  PRIMARY_SHARD(ctx);
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -432,6 +504,8 @@ extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t
   if (!ctx || !b || (!xy_be && n)) return BN256_EINVAL;
   if (off > b->n || n > b->n - off) return BN256_ELENGTH;
   if (!n) return BN256_OK;
+  if (b->nshard) return multi_bases_download(ctx, b, off, n, xy_be);
+  PRIMARY_SHARD(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   int rc = ws_reserve(ctx, WS_TMP, n * 64);
   if (rc) return rc;
@@ -728,6 +802,7 @@ static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t str
 }
 
 static int range_check(const bn256_bases* b, size_t off, size_t n, size_t stride = 1) {
+  if (b->nshard) return BN256_ENOTSUP;  // a sharded handle reaches the device only through the multi_* paths
   if (stride == 0) return BN256_EINVAL;
   if (off > b->n) return BN256_ELENGTH;
   if (n == 0) return BN256_OK;
@@ -739,6 +814,7 @@ static int range_check(const bn256_bases* b, size_t off, size_t n, size_t stride
 extern "C" int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                              uint8_t out_xy_be[64]) {
   if (!ctx || !b || !out_xy_be || (!d_scalars_be && n)) return BN256_EINVAL;
+  if (ctx->nshard || b->nshard) return multi_msm(ctx, b, off, n, (const uint8_t*)d_scalars_be, true, out_xy_be);
   int rc = range_check(b, off, n);
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
@@ -754,6 +830,7 @@ extern "C" int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, s
 extern "C" int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n,
                                      const void* d_scalars_be, uint8_t out_xy_be[64]) {
   if (!ctx || !b || !out_xy_be || (!d_scalars_be && n)) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   int rc = range_check(b, off, n);
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
@@ -791,6 +868,7 @@ extern "C" int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_
 extern "C" int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                                 int* ticket) {
   if (!ctx || !b || !ticket || (!d_scalars_be && n)) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *ticket = -1;
   int rc = range_check(b, off, n);
   if (rc) return rc;
@@ -818,6 +896,7 @@ extern "C" int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off
 extern "C" int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]) {
   if (!ctx || !out_xy_be || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket] || ctx->pending[ticket]->fold)
     return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   bn256_ctx* lane = ctx->lane[ticket];
   msm_pending* pend = ctx->pending[ticket];
@@ -850,6 +929,7 @@ static int msm_host_scalars(bn256_ctx* ctx, const bn256_bases* b, size_t off, si
 extern "C" int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
                          uint8_t out_xy_be[64]) {
   if (!ctx || !b || !out_xy_be || (!scalars_be && n)) return BN256_EINVAL;
+  if (ctx->nshard || b->nshard) return multi_msm(ctx, b, off, n, scalars_be, false, out_xy_be);
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt r;
   int rc = msm_host_scalars(ctx, b, off, 1, n, scalars_be, &r);
@@ -921,6 +1001,7 @@ extern "C" int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases*
                                        const size_t* stride, const size_t* n, const uint8_t* const* scalars_be,
                                        uint8_t out_xy_be[64]) {
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   {
     msm_pending pend;
@@ -956,6 +1037,7 @@ extern "C" int bn256_msm_multi(bn256_ctx* ctx, int k, const bn256_bases* const* 
 extern "C" int bn256_msm_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,
                                       const size_t* n, const uint8_t* const* scalars_be, int* ticket) {
   if (!ctx || k < 0 || !ticket || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *ticket = -1;
   HIPCHK(hipSetDevice(ctx->device));
   int l = 0, rc;
@@ -1192,6 +1274,7 @@ static int fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32
 extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
                                       const uint8_t* scalars_be, int broadcast, bn256_bases** out) {
   if (!ctx || !in || !out || (!scalars_be && n)) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *out = nullptr;
   int rc = range_check(in, off, n);
   if (rc) return rc;
@@ -1235,6 +1318,7 @@ extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, siz
 extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn256_bases* b, size_t boff,
                                size_t n, bn256_bases** out) {
   if (!ctx || !a || !b || !out) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *out = nullptr;
   int rc = range_check(a, aoff, n);
   if (rc) return rc;
@@ -1258,6 +1342,7 @@ extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff
 extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const uint8_t h_xy_be[64],
                                const uint8_t* a_be, const uint8_t* b_be, size_t n, bn256_bases** out) {
   if (!ctx || !g_xy_be || !h_xy_be || !out || ((!a_be || !b_be) && n)) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *out = nullptr;
   if (n >= (1ull << 29)) return BN256_ETOOLARGE;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1327,6 +1412,7 @@ extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off,
                            size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32],
                            const uint8_t s_hi_be[32], bn256_bases** out) {
   if (!ctx || !lo || !hi || !out || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   int rc = fold2_enqueue(ctx, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, out);
   if (rc) return rc;
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -1343,6 +1429,7 @@ extern "C" int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t 
                                   const bn256_bases* hi, size_t hi_off, size_t n_hi, size_t stride,
                                   const uint8_t s_lo_be[32], const uint8_t s_hi_be[32], bn256_bases** out, int* ticket) {
   if (!ctx || !lo || !hi || !out || !ticket || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *out = nullptr;
   *ticket = -1;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1367,6 +1454,7 @@ extern "C" int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t 
 extern "C" int bn256_fold_wait(bn256_ctx* ctx, int ticket) {
   if (!ctx || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket] || !ctx->pending[ticket]->fold)
     return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   delete ctx->pending[ticket];
   ctx->pending[ticket] = nullptr;
@@ -1387,6 +1475,7 @@ extern "C" int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, 
 // ---------------------------------------------------------------------------- synthetic
 extern "C" int bn256_random_scalars(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, void* d_out_be) {
   if (!ctx || (!d_out_be && n)) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   if (n >= (1ull << 32)) return BN256_ETOOLARGE;
   HIPCHK(hipSetDevice(ctx->device));
   if (n) {
@@ -1401,6 +1490,7 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
   if (!ctx || !out) return BN256_EINVAL;
   *out = nullptr;
   if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  if (ctx->nshard) return multi_bases_make(ctx, nullptr, true, seed, first, n, flags, out);
   HIPCHK(hipSetDevice(ctx->device));
   bool precomp = (flags & BN256_PRECOMPUTE) != 0 && n > 0;
   int c = precomp ? pick_c(ctx, n, true) : 0;
@@ -1479,6 +1569,7 @@ static bn256_frvec* frvec_alloc(size_t n, int* rc) {
 
 extern "C" void bn256_fr_free(bn256_ctx* ctx, bn256_frvec* v) {
   if (!v) return;
+  PRIMARY_SHARD(ctx);
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -1492,6 +1583,7 @@ extern "C" const void* bn256_fr_device_ptr(const bn256_frvec* v) { return v ? v-
 
 extern "C" int bn256_fr_upload(bn256_ctx* ctx, const uint8_t* scalars_be, size_t n, bn256_frvec** out) {
   if (!ctx || !out || (!scalars_be && n)) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   *out = nullptr;
   if (n >= (1ull << 31)) return BN256_ETOOLARGE;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1509,6 +1601,7 @@ extern "C" int bn256_fr_upload(bn256_ctx* ctx, const uint8_t* scalars_be, size_t
 
 extern "C" int bn256_fr_random(bn256_ctx* ctx, uint64_t seed, size_t first, size_t n, bn256_frvec** out) {
   if (!ctx || !out) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   *out = nullptr;
   if (n >= (1ull << 31)) return BN256_ETOOLARGE;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1523,6 +1616,7 @@ extern "C" int bn256_fr_random(bn256_ctx* ctx, uint64_t seed, size_t first, size
 
 extern "C" int bn256_fr_download(bn256_ctx* ctx, const bn256_frvec* v, size_t off, size_t n, uint8_t* scalars_be) {
   if (!ctx || !v || (!scalars_be && n)) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   if (off > v->n || n > v->n - off) return BN256_ELENGTH;
   HIPCHK(hipSetDevice(ctx->device));
   if (n) {
@@ -1568,6 +1662,7 @@ extern "C" int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off,
                              size_t b_off, size_t n_b, size_t stride, const uint8_t s_a_be[32],
                              const uint8_t s_b_be[32], bn256_frvec** out) {
   if (!ctx || !a || !b || !out || !s_a_be || !s_b_be) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   *out = nullptr;
   int rc;
   if ((rc = fr_range_check(a, a_off, n_a, stride)) || (rc = fr_range_check(b, b_off, n_b, stride))) return rc;
@@ -1591,6 +1686,7 @@ extern "C" int bn256_fr_dot(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, 
                             const bn256_frvec* b, size_t b_off, size_t b_stride, size_t n_b, const uint8_t* mu_be,
                             uint8_t out_be[32]) {
   if (!ctx || !a || !b || !out_be) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   int rc;
   if ((rc = fr_range_check(a, a_off, n_a, a_stride)) || (rc = fr_range_check(b, b_off, n_b, b_stride))) return rc;
   memset(out_be, 0, 32);
@@ -1619,6 +1715,11 @@ extern "C" int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, si
                             const bn256_frvec* v, size_t v_off, size_t v_stride, uint8_t out_xy_be[64]) {
   if (!ctx || !b || !v || !out_xy_be) return BN256_EINVAL;
   int rc;
+  if (ctx->nshard || b->nshard) {  // the Fr vector lives on the first device; contiguous views only
+    if (stride != 1 || v_stride != 1) return BN256_ENOTSUP;
+    if ((rc = fr_range_check(v, v_off, n, 1))) return rc;
+    return multi_msm(ctx, b, off, n, v->d + v_off * 32, true, out_xy_be);
+  }
   if ((rc = range_check(b, off, n, stride)) || (rc = fr_range_check(v, v_off, n, v_stride))) return rc;
   HIPCHK(hipSetDevice(ctx->device));
   hostg1::Pt r;
@@ -1672,6 +1773,7 @@ extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* cons
                                   const size_t* v_off, const size_t* v_stride, const uint8_t* const* scale_be,
                                   uint8_t out_xy_be[64]) {
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   memset(out_xy_be, 0, 64);
   msm_pending pend;
   int rc = fr_multi_enqueue(ctx, k, b, off, stride, n, v, v_off, v_stride, scale_be, false, &pend);
@@ -1687,6 +1789,7 @@ extern "C" int bn256_msm_fr_multi_submit(bn256_ctx* ctx, int k, const bn256_base
                                          const size_t* v_off, const size_t* v_stride, const uint8_t* const* scale_be,
                                          int* ticket) {
   if (!ctx || k < 0 || !ticket || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
+  SINGLE_DEVICE_ONLY(ctx);
   *ticket = -1;
   HIPCHK(hipSetDevice(ctx->device));
   int l = 0, rc;
@@ -1724,6 +1827,7 @@ extern "C" int bn256_g1_sum(const uint8_t* xy_be, size_t k, uint8_t out_xy_be[64
 
 extern "C" int bn256_selftest(bn256_ctx* ctx) {
   if (!ctx) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, 4, ctx->stream));
   const u32 n = 1u << 16;
@@ -1731,4 +1835,102 @@ extern "C" int bn256_selftest(bn256_ctx* ctx) {
   HIPCHK(hipMemcpyAsync(ctx->h_err, ctx->d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return (int)ctx->h_err[0];
+}
+
+// ---------------------------------------------------------------------------- multi-device contexts
+// bn256_ctx_create_multi: the reference's caller is ONE goroutine in one process
+// (go/bp/main.go:81-178), so a drop-in that is to use the whole node must shard inside the library:
+// a handle made by such a context holds contiguous slices of the points, one per device of the list,
+// an MSM runs every shard's pipeline side by side (one host thread per shard: its scalar upload,
+// enqueue and host tail) and the <= 8 partial points are added on the host.  Nothing crosses between
+// the devices but the caller's scalars on their way in (and 64 bytes per shard on the way out).
+template <class F>
+static int for_each_shard(int nshard, F fn) {
+  int rcs[BN256_MAX_DEVICES] = {0};
+  char msgs[BN256_MAX_DEVICES][sizeof g_hip_msg];
+  std::thread th[BN256_MAX_DEVICES];
+  for (int s = 1; s < nshard; s++)
+    th[s] = std::thread([&, s] {
+      g_hip_msg[0] = 0;
+      rcs[s] = fn(s);
+      memcpy(msgs[s], g_hip_msg, sizeof g_hip_msg);  // thread_local: carried back to the caller's thread
+    });
+  rcs[0] = fn(0);
+  for (int s = 1; s < nshard; s++) th[s].join();
+  for (int s = 0; s < nshard; s++)
+    if (rcs[s]) {
+      if (s) memcpy(g_hip_msg, msgs[s], sizeof g_hip_msg);
+      return rcs[s];
+    }
+  return BN256_OK;
+}
+
+static int multi_bases_make(bn256_ctx* ctx, const uint8_t* xy_be, bool synth, uint64_t seed, size_t first, size_t n,
+                            int flags, bn256_bases** out) {
+  bn256_bases* b = new (std::nothrow) bn256_bases();
+  if (!b) return BN256_ENOMEM;
+  b->n = n;
+  b->nshard = ctx->nshard;
+  const size_t base = n / ctx->nshard, rem = n % ctx->nshard;  // the first n % nshard shards hold one more
+  for (int s = 0; s <= ctx->nshard; s++) b->shard_off[s] = (size_t)s * base + std::min<size_t>((size_t)s, rem);
+  int rc = for_each_shard(ctx->nshard, [&](int s) {
+    const size_t lo = b->shard_off[s], m = b->shard_off[s + 1] - lo;
+    return synth ? bn256_random_bases(ctx->shard[s], seed, first + lo, m, flags, &b->shard[s])
+                 : bn256_bases_upload(ctx->shard[s], xy_be + 64 * lo, m, flags, &b->shard[s]);
+  });
+  if (rc) {
+    multi_bases_free(ctx, b);
+    return rc;
+  }
+  *out = b;
+  return BN256_OK;
+}
+
+static void multi_bases_free(bn256_ctx* ctx, bn256_bases* b) {
+  for (int s = 0; s < b->nshard; s++)
+    bn256_bases_free(ctx && ctx->nshard == b->nshard ? ctx->shard[s] : nullptr, b->shard[s]);
+  delete b;
+}
+
+static int multi_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be) {
+  if (!ctx->nshard || ctx->nshard != b->nshard) return BN256_EINVAL;
+  for (int s = 0; s < b->nshard; s++) {
+    const size_t lo = std::max(off, b->shard_off[s]), hi = std::min(off + n, b->shard_off[s + 1]);
+    if (lo >= hi) continue;
+    int rc = bn256_bases_download(ctx->shard[s], b->shard[s], lo - b->shard_off[s], hi - lo, xy_be + 64 * (lo - off));
+    if (rc) return rc;
+  }
+  return BN256_OK;
+}
+
+// scalars: host memory, or (on_device) memory of any one GPU -- a shard on another device copies its
+// slice over the peer link first
+static int multi_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars, bool on_device,
+                     uint8_t out_xy_be[64]) {
+  if (!ctx->nshard || ctx->nshard != b->nshard) return BN256_EINVAL;  // handle and context must be of one kind
+  if (off > b->n || n > b->n - off) return BN256_ELENGTH;
+  int src_dev = -1;
+  if (on_device && n) {
+    hipPointerAttribute_t attr;
+    HIPCHK(hipPointerGetAttributes(&attr, scalars));
+    src_dev = attr.device;
+  }
+  uint8_t parts[BN256_MAX_DEVICES][64];
+  int rc = for_each_shard(ctx->nshard, [&](int s) -> int {
+    memset(parts[s], 0, 64);
+    const size_t lo = std::max(off, b->shard_off[s]), hi = std::min(off + n, b->shard_off[s + 1]);
+    if (lo >= hi) return BN256_OK;
+    bn256_ctx* c = ctx->shard[s];
+    const size_t m = hi - lo, loc = lo - b->shard_off[s];
+    const uint8_t* src = scalars + 32 * (lo - off);
+    if (!on_device) return bn256_msm(c, b->shard[s], loc, m, src, parts[s]);
+    if (src_dev == c->device) return bn256_msm_dev(c, b->shard[s], loc, m, src, parts[s]);
+    HIPCHK(hipSetDevice(c->device));
+    int r = ws_reserve(c, WS_SCALARS, m * 32);
+    if (r) return r;
+    HIPCHK(hipMemcpyPeerAsync(c->ws[WS_SCALARS], c->device, src, src_dev, m * 32, c->stream));
+    return bn256_msm_dev(c, b->shard[s], loc, m, c->ws[WS_SCALARS], parts[s]);  // same stream: ordered after the copy
+  });
+  if (rc) return rc;
+  return bn256_g1_sum(&parts[0][0], (size_t)ctx->nshard, out_xy_be);
 }

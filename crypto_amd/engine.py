@@ -84,10 +84,17 @@ class FrVec:
 
 
 class Engine:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices: Sequence[int] | None = None):
+        """One GPU (`device`), or -- devices=[...] -- ONE context over several GPUs of the node
+        (bn256_ctx_create_multi: handles are sharded by contiguous slice, msm / msm_dev / msm_fr run
+        every slice side by side and add the partial points on the host)."""
         self.lib = _lib.load()
         ctx = C.c_void_p()
-        rc = self.lib.bn256_ctx_create(device, C.byref(ctx))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.bn256_ctx_create_multi(arr, len(devices), C.byref(ctx))
+        else:
+            rc = self.lib.bn256_ctx_create(device, C.byref(ctx))
         if rc:
             raise BN256Error(rc, self.lib.bn256_strerror(rc).decode())
         self.ctx = ctx

@@ -37,6 +37,7 @@ typedef struct bn256_bases bn256_bases;
 #define BN256_ENOMEM (-6)
 #define BN256_ETOOLARGE (-7)   /* n * windows exceeds 2^31 entries */
 #define BN256_EBUSY (-8)       /* bn256_msm_submit: every lane holds a submitted call */
+#define BN256_ENOTSUP (-10)    /* entry point not served by a multi-device context / sharded handle */
 #define BN256_ESCRATCH (-9)    /* bn256_msm_dev_noalloc: the call does not fit the static scratch array */
 
 /* bn256_bases_upload flags */
@@ -45,6 +46,21 @@ typedef struct bn256_bases bn256_bases;
 /* Opens GPU `device` (HIP ordinal).  Owns one stream and the scratch buffers. */
 int bn256_ctx_create(int device, bn256_ctx** out);
 void bn256_ctx_destroy(bn256_ctx* ctx);
+/* One context over 1..BN256_MAX_DEVICES GPUs of the node, for the reference's caller as it is: one
+ * goroutine in one process (go/bp/main.go:81-178) that cannot become a process per GPU.  A handle made
+ * by such a context (bn256_bases_upload, bn256_random_bases) holds contiguous slices of the points,
+ * slice s on devices[s] (the first n % ndev slices hold one point more; the same device may be listed
+ * more than once); bn256_msm / bn256_msm_dev / bn256_msm_fr (contiguous views) run every slice's
+ * pipeline side by side and add the <= 8 partial points on the host, so vectorPointScalarMul
+ * (go/bp/util.go:165-175) uses the node through the same call.  Host scalars go to each device over
+ * its own PCIe link; a device pointer may live on any one GPU (the other shards copy their slices
+ * over the peer link).  Fr vectors, bn256_random_scalars and bn256_selftest of such a context live on
+ * devices[0]; bn256_bases_free / _len / _download, bn256_ctx_set_tuning and bn256_last_timing (slowest
+ * shard) work as usual; every other entry point returns BN256_ENOTSUP (the element-wise kernels
+ * shard trivially but are not wired up).  The process-per-GPU form (bench.py, RCCL all_gather of the
+ * partials + bn256_g1_sum) needs nothing of this. */
+#define BN256_MAX_DEVICES 8
+int bn256_ctx_create_multi(const int* devices, int ndev, bn256_ctx** out);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */
 void* bn256_ctx_stream(bn256_ctx* ctx);
 
