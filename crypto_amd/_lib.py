@@ -14,7 +14,7 @@ EXPORTS = [
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
-    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait",
+    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait", "bn256_ctx_drain",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
                                            C.POINTER(C.c_int)]
     lib.bn256_fold2_submit.argtypes = [vp, vp, sz, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp), C.POINTER(C.c_int)]
     lib.bn256_fold_wait.argtypes = [vp, i]
+    lib.bn256_ctx_drain.argtypes = [vp]
     lib.bn256_glv_split.argtypes = [u8p, u8p, C.POINTER(C.c_int), u8p, C.POINTER(C.c_int)]
     lib.bn256_g1_sum.argtypes = [u8p, sz, u8p]
     lib.bn256_ctx_set_tuning.argtypes = [vp, i, i]

@@ -8,7 +8,7 @@ from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPAMD_LIB") or os.path.join(_HERE, "libbpamd.so")  # override: A/B builds
-EXPORTS = ["bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
+EXPORTS = ["bp_setup", "bp_prove", "bp_verify", "bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
            "bp_wnla_det", "bp_wnla_synthetic", "bp_ac_det"]
 _bp = None
 
@@ -29,6 +29,10 @@ def load() -> C.CDLL:
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m crypto_amd.build`")
     lib = C.CDLL(LIB_PATH)
     vp, sz = C.c_void_p, C.c_size_t
+    lib.bp_setup.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.bp_prove.argtypes = [vp, C.c_int, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz,
+                             C.POINTER(sz)]
+    lib.bp_verify.argtypes = [vp, C.c_int, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]
     lib.bp_prove_det.argtypes = [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_char_p, sz, C.POINTER(sz)]
     lib.bp_verify_det.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, sz]
     lib.bp_inner_product_roundtrip.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int]
@@ -42,8 +46,45 @@ def load() -> C.CDLL:
     return lib
 
 
+class BulletProofPublic:
+    """NewBulletProofPublic / Prove / Verify (go/bp/main.go:27-34, :81-249), the product form: generators
+    resident on the device, U, g, h as Marshal() bytes, all randomness from the OS CSPRNG (bp_setup /
+    bp_prove / bp_verify).  Proofs are randomised; see BulletProofs below for the seeded test harness."""
+
+    def __init__(self, engine, n: int, G=None, H=None, U: bytes | None = None, g: bytes | None = None,
+                 h: bytes | None = None):
+        from .engine import Bases
+        self.eng, self.lib, self.n = engine, load(), n
+        if G is None:
+            hg, hh = C.c_void_p(), C.c_void_p()
+            bu, bg, bh = (C.create_string_buffer(64) for _ in range(3))
+            rc = self.lib.bp_setup(engine.ctx, n, C.byref(hg), C.byref(hh), bu, bg, bh)
+            if rc:
+                raise RuntimeError(f"bp_setup rc={rc}: {self.lib.bp_last_error().decode()}")
+            self.G, self.H, self.U, self.g, self.h = Bases(engine, hg), Bases(engine, hh), bu.raw, bg.raw, bh.raw
+        else:
+            self.G, self.H, self.U, self.g, self.h = G, H, U, g, h
+
+    def prove(self, v: int, prv: int) -> bytes:
+        cap = 64 * 5 + 32 * 5 + 4 + 128 * 64
+        out = C.create_string_buffer(cap)
+        ln = C.c_size_t(0)
+        rc = self.lib.bp_prove(self.eng.ctx, self.n, self.G.h, self.H.h, self.U, self.g, self.h,
+                               int(v).to_bytes(32, "big"), int(prv).to_bytes(32, "big"), out, cap, C.byref(ln))
+        if rc:
+            raise RuntimeError(f"bp_prove rc={rc}: {self.lib.bp_last_error().decode()}")
+        return out.raw[:ln.value]
+
+    def verify(self, proof: bytes) -> str | None:
+        """None when accepted, else the reference's error string."""
+        rc = self.lib.bp_verify(self.eng.ctx, self.n, self.G.h, self.H.h, self.U, self.g, self.h, proof, len(proof))
+        return None if rc == 0 else self.lib.bp_last_error().decode()
+
+
 class BulletProofs:
-    """NewBulletProofPublic / Prove / Verify (go/bp/main.go) with an injected, seeded reader."""
+    """TEST HARNESS: NewBulletProofPublic / Prove / Verify (go/bp/main.go) with an injected, seeded reader
+    (bp_prove_det / bp_verify_det).  The seed fixes generators (known discrete logs) and blinding alike and
+    is shared with the verifier: reproducible transcripts for parity tests, neither sound nor hiding."""
 
     def __init__(self, engine):
         self.eng = engine

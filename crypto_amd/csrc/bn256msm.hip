@@ -71,6 +71,22 @@ static std::multimap<size_t, void*> g_free[16];  // per device: capacity -> bloc
 static size_t g_cached[16];
 static int g_contexts;
 
+// BN256_FAIL_ALLOC_ABOVE=<bytes> (environment, read once): every device allocation larger than that
+// fails with hipErrorOutOfMemory -- lets the tests walk the out-of-memory paths without filling a GPU
+static size_t alloc_limit() {
+  static const size_t v = [] {
+    const char* e = getenv("BN256_FAIL_ALLOC_ABOVE");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
+  }();
+  return v;
+}
+static hipError_t dev_malloc(void** out, size_t bytes) {
+  if (alloc_limit() && bytes > alloc_limit()) {
+    *out = nullptr;
+    return hipErrorOutOfMemory;
+  }
+  return hipMalloc(out, bytes);
+}
 static hipError_t alloc(void** out, size_t bytes, size_t* cap, int* dev) {
   int d = 0;
   hipError_t e = hipGetDevice(&d);
@@ -89,7 +105,7 @@ static hipError_t alloc(void** out, size_t bytes, size_t* cap, int* dev) {
     }
   }
   *cap = bytes;
-  e = hipMalloc(out, bytes);
+  e = dev_malloc(out, bytes);
   if (e == hipErrorOutOfMemory && d >= 0 && d < 16) {  // give the cache back and try once more
     {
       std::lock_guard<std::mutex> lk(g_mu);
@@ -97,7 +113,7 @@ static hipError_t alloc(void** out, size_t bytes, size_t* cap, int* dev) {
       g_free[d].clear();
       g_cached[d] = 0;
     }
-    e = hipMalloc(out, bytes);
+    e = dev_malloc(out, bytes);
   }
   return e;
 }
@@ -214,7 +230,7 @@ static int ws_reserve(bn256_ctx* ctx, int which, size_t bytes) {
     ctx->cap[which] = 0;
   }
   size_t want = bytes + bytes / 8 + 256;
-  hipError_t e = hipMalloc(&ctx->ws[which], want);
+  hipError_t e = pool::dev_malloc(&ctx->ws[which], want);
   if (e != hipSuccess) {
     ctx_note_hip(e, __LINE__);
     return e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
@@ -273,8 +289,14 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
 static int ctx_init(bn256_ctx* ctx) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
-  HIPCHK(hipMalloc(&ctx->d_err, 256));
-  HIPCHK(hipMalloc(&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32)));
+  for (int i = 0; i < 2; i++) {
+    hipError_t e = i == 0 ? pool::dev_malloc((void**)&ctx->d_err, 256)
+                          : pool::dev_malloc((void**)&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32));
+    if (e != hipSuccess) {
+      ctx_note_hip(e, __LINE__);
+      return e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
+    }
+  }
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
@@ -737,6 +759,7 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
                            (const xyzz_mem*)buckets, (u32)nbt);
     }
     HIPCHK(hipEventRecord(ctx->ev[5], s));
+    HIPCHK(hipGetLastError());  // a failed launch is reported with its own pass, not after all of them
     if (ch + 1 < nchunks && !hold_stream) {  // per-pass phase times; the last pass is read after the reduction
       HIPCHK(hipStreamSynchronize(s));
       for (int i = 0; i < 5; i++) {
@@ -1448,6 +1471,30 @@ extern "C" int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t 
   }
   ctx->pending[l] = pend;
   *ticket = l;
+  return BN256_OK;
+}
+
+extern "C" int bn256_ctx_drain(bn256_ctx* ctx) {
+  if (!ctx) return BN256_EINVAL;
+  if (ctx->nshard) {
+    int rc = BN256_OK;
+    for (int s = 0; s < ctx->nshard; s++) {
+      int r = bn256_ctx_drain(ctx->shard[s]);
+      if (r && !rc) rc = r;
+    }
+    return rc;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  hipError_t first = hipStreamSynchronize(ctx->stream);
+  for (int l = 0; l < BN256_ASYNC_LANES; l++) {
+    if (ctx->lane[l]) {
+      hipError_t e = hipStreamSynchronize(ctx->lane[l]->stream);
+      if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    pending_free(ctx->pending[l]);  // the ticket is void from here on
+    ctx->pending[l] = nullptr;
+  }
+  HIPCHK(first);
   return BN256_OK;
 }
 

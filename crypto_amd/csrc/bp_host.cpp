@@ -15,6 +15,9 @@
 #include <string>
 #include <vector>
 
+#include <errno.h>
+#include <sys/random.h>
+
 #include "../../include/bn256msm.h"
 #include "../../include/bp_amd.h"
 #include "host_g1.h"
@@ -301,9 +304,28 @@ Fr hashFS(const FrVec& scalars, const std::vector<Point>& points) {
 // ------------------------------------------------------------------ crypto/rand stand-in
 // rand.Reader replacement for deterministic transcripts: SplitMix64, 8 bytes
 // big-endian per step; rand.Int = read 32 bytes, accept iff < Order.
+// With os_random the 8 bytes come from the operating system's CSPRNG instead (getrandom(2)): what
+// crypto/rand.Reader is in the reference (go/bp/util.go:51-63) -- the product entry points bp_setup /
+// bp_prove use that; the seeded stream exists for reproducible transcripts in the tests only.
 struct ByteStream {
   uint64_t s;
+  bool os_random = false;
   uint64_t next64() {
+    if (os_random) {
+      uint8_t b[8];
+      size_t got = 0;
+      while (got < sizeof b) {
+        ssize_t r = getrandom(b + got, sizeof b - got, 0);
+        if (r < 0) {
+          if (errno == EINTR) continue;
+          throw std::runtime_error("getrandom failed");
+        }
+        got += (size_t)r;
+      }
+      uint64_t z = 0;
+      for (int i = 0; i < 8; i++) z = (z << 8) | b[i];
+      return z;
+    }
     s += 0x9E3779B97F4A7C15ULL;
     uint64_t z = s;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -1322,6 +1344,7 @@ extern "C" int bp_prove_det(bn256_ctx* ctx, int n, const uint8_t v_be[32], uint6
     return 0;
   } catch (const std::exception& e) {
     g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
     return BP_EFAIL;
   }
 }
@@ -1341,6 +1364,100 @@ extern "C" int bp_verify_det(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t
     return e.empty() ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
+    return BP_EFAIL;
+  }
+}
+
+// ---- product entry points: the caller's generators (resident handles), blinding from the OS CSPRNG
+namespace {
+// a []*bn256.G1 the caller owns, seen as DevPoints for the duration of a call
+struct Borrowed {
+  DevPoints d;
+  Borrowed(bn256_ctx* c, const bn256_bases* b) : d(c, const_cast<bn256_bases*>(b)) {}
+  ~Borrowed() { d.h = nullptr; }
+};
+bool pointOk(const uint8_t b[64]) {
+  hostg1::Pt t;
+  return hostg1::unmarshal(t, b) == 0;
+}
+BulletProofPublic publicFrom(bn256_ctx* ctx, int n, const bn256_bases* G, const bn256_bases* H, const uint8_t U[64],
+                             const uint8_t g[64], const uint8_t h[64]) {
+  if (bn256_bases_len(G) != (size_t)n || bn256_bases_len(H) != (size_t)n) throw std::runtime_error("invalid length for scalar mul");
+  if (!pointOk(U) || !pointOk(g) || !pointOk(h)) throw std::runtime_error("bn256: malformed point");
+  BulletProofPublic p;
+  p.N = n;
+  Borrowed bg(ctx, G), bh(ctx, H);
+  p.G = cloneRange(ctx, bg.d);
+  p.H = cloneRange(ctx, bh.d);
+  memcpy(p.U.b, U, 64);
+  memcpy(p.g.b, g, 64);
+  memcpy(p.h.b, h, 64);
+  return p;
+}
+}  // namespace
+
+extern "C" int bp_setup(bn256_ctx* ctx, int n, bn256_bases** G, bn256_bases** H, uint8_t U[64], uint8_t g[64],
+                        uint8_t h[64]) {
+  try {
+    if (!ctx || !G || !H || !U || !g || !h || n < 1) return BN256_EINVAL;
+    *G = *H = nullptr;
+    ByteStream rd{0};
+    rd.os_random = true;
+    BulletProofPublic pub = newBulletProofPublic(ctx, rd, n);
+    *G = pub.G.h;
+    *H = pub.H.h;
+    pub.G.h = pub.H.h = nullptr;  // ownership passes to the caller
+    memcpy(U, pub.U.b, 64);
+    memcpy(g, pub.g.b, 64);
+    memcpy(h, pub.h.b, 64);
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
+    return BP_EFAIL;
+  }
+}
+
+extern "C" int bp_prove(bn256_ctx* ctx, int n, const bn256_bases* G, const bn256_bases* H, const uint8_t U[64],
+                        const uint8_t g[64], const uint8_t h[64], const uint8_t v_be[32], const uint8_t prv_be[32],
+                        uint8_t* out, size_t cap, size_t* out_len) {
+  try {
+    if (!ctx || !G || !H || !U || !g || !h || !v_be || !prv_be || !out || !out_len || n < 1) return BN256_EINVAL;
+    BulletProofPublic pub = publicFrom(ctx, n, G, H, U, g, h);
+    ByteStream rd{0};
+    rd.os_random = true;  // alpha, sl, sr, ro, tau1, tau2: crypto/rand in the reference (go/bp/main.go:87-123)
+    BulletProof pr = prove(ctx, pub, fr_from_be(v_be), fr_from_be(prv_be), rd);
+    std::vector<uint8_t> ser = serialize(pr);
+    *out_len = ser.size();
+    if (ser.size() > cap) return BN256_ELENGTH;
+    memcpy(out, ser.data(), ser.size());
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
+    return BP_EFAIL;
+  }
+}
+
+extern "C" int bp_verify(bn256_ctx* ctx, int n, const bn256_bases* G, const bn256_bases* H, const uint8_t U[64],
+                         const uint8_t g[64], const uint8_t h[64], const uint8_t* proof, size_t len) {
+  try {
+    if (!ctx || !G || !H || !U || !g || !h || !proof || n < 1) return BN256_EINVAL;
+    BulletProofPublic pub = publicFrom(ctx, n, G, H, U, g, h);
+    BulletProof pr;
+    if (!deserialize(pr, proof, len)) {
+      g_err = "malformed proof encoding";
+      return BP_EFAIL;
+    }
+    std::string e = verify(ctx, pub, pr);
+    g_err = e;
+    return e.empty() ? 0 : BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
     return BP_EFAIL;
   }
 }
@@ -1367,6 +1484,7 @@ extern "C" int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, 
     return e.empty() ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
     return BP_EFAIL;
   }
 }
@@ -1413,6 +1531,7 @@ extern "C" int bp_wnla_det(bn256_ctx* ctx, uint64_t seed, int nl, int nn, const 
     return r.verified ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
     return BP_EFAIL;
   }
 }
@@ -1507,6 +1626,7 @@ extern "C" int bp_ac_det(bn256_ctx* ctx, uint64_t seed, int pre_draws, int post_
     return T.w.verified ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
     return BP_EFAIL;
   }
 }
@@ -1549,6 +1669,7 @@ extern "C" int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_
     return r.verified ? 0 : BP_EVERIFY;
   } catch (const std::exception& e) {
     g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
     return BP_EFAIL;
   }
 }

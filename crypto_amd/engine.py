@@ -216,6 +216,26 @@ class Engine:
         a = list(a)[:n] + [0] * max(0, n - len(a))
         return self.msm(g, a)
 
+    def inner_product_h(self, n: int, g: Bases, h: Bases, u: "Bases | bytes", a: Sequence[int], a1: Sequence[int],
+                        b: Sequence[int], b1: Sequence[int], c: int) -> bytes:
+        """InnerProductH, go/bp/util.go:15-27: <a, g[:n/2]> + <a1, g[n/2:]> + <b, h[:n/2]> + <b1, h[n/2:]> + c*u
+        as ONE device MSM of five segments.  Odd n panics "invalid n" there; each half goes through
+        vectorPointScalarMul, whose length check (go/bp/util.go:166-168) is kept."""
+        if n % 2 != 0:
+            raise ValueError("invalid n")
+        n1 = n // 2
+        if len(g) < n1 or len(h) < n1 or len(a) != n1 or len(b) != n1 or len(a1) != len(g) - n1 or len(b1) != len(h) - n1:
+            raise ValueError("invalid length for scalar mul")
+        own = not isinstance(u, Bases)
+        uh = self.upload(u) if own else u
+        try:
+            if len(uh) != 1:
+                raise ValueError("u must be a single point")
+            return self.msm_multi([(g, 0, a), (g, n1, a1), (h, 0, b), (h, n1, b1), (uh, 0, [c])])
+        finally:
+            if own:
+                uh.free()
+
     def vector_point_mul_on_scalar(self, g: Bases, a: int, off: int = 0, n: int | None = None) -> Bases:
         """vectorPointMulOnScalar, go/bp/util.go:177-183."""
         n = len(g) - off if n is None else n
@@ -261,6 +281,10 @@ class Engine:
                                               int(s_lo).to_bytes(32, "big"), int(s_hi).to_bytes(32, "big"),
                                               C.byref(h), C.byref(t)))
         return Bases(self, h), t.value
+
+    def drain(self) -> None:
+        """Waits for everything enqueued and voids all outstanding tickets (bn256_ctx_drain)."""
+        self._chk(self.lib.bn256_ctx_drain(self.ctx))
 
     def fold_wait(self, ticket: int) -> None:
         self._chk(self.lib.bn256_fold_wait(self.ctx, ticket))

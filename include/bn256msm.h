@@ -177,6 +177,12 @@ int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, siz
                        bn256_bases** out, int* ticket);
 int bn256_fold_wait(bn256_ctx* ctx, int ticket);
 
+/* Waits for everything this context has enqueued and voids every outstanding ticket (submitted MSMs
+ * and folds; a handle returned by bn256_fold2_submit keeps its memory and is freed as usual).  For a
+ * caller that lost a ticket on an error path -- an exception between submit and wait -- and must not
+ * leave its lane busy: without this, three such losses make every submit return BN256_EBUSY. */
+int bn256_ctx_drain(bn256_ctx* ctx);
+
 /* Marshal() of n points of a handle into host memory. */
 int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be);
 

@@ -21,7 +21,31 @@ extern "C" {
 #define BP_EFAIL (-20)   /* exception text in bp_last_error() */
 #define BP_EVERIFY (-21) /* Verify returned an error; the reference's message in bp_last_error() */
 
-/* NewBulletProofPublic(n) from the seeded reader, prv := next rand.Int, then
+/* ---- Product entry points -------------------------------------------------------------------------
+ * The reference draws its generators and every blinding value from crypto/rand (go/bp/util.go:51-63,
+ * :81-90) and keeps no discrete logarithm.  These three do the same: randomness comes from the
+ * operating system's CSPRNG (getrandom(2)), generators are the caller's (resident handles), nothing is
+ * derived from a seed.
+ *   bp_setup   NewBulletProofPublic(n), go/bp/main.go:27-34: G[n], H[n] as new handles (the caller frees
+ *              them with bn256_bases_free), U, g, h as Marshal() bytes; the k of k*G0 are discarded.
+ *   bp_prove   (*BulletProofPublic).Prove(v, prv), go/bp/main.go:81-178; same wire format as below.
+ *   bp_verify  (*BulletProofPublic).Verify, go/bp/main.go:181-249: 0 = accepted, BP_EVERIFY = rejected.
+ * Proofs are randomised, so their test is prove -> verify (here and by the oracle's restatement of
+ * Verify), not byte equality. */
+int bp_setup(bn256_ctx* ctx, int n, bn256_bases** G, bn256_bases** H, uint8_t U[64], uint8_t g[64], uint8_t h[64]);
+int bp_prove(bn256_ctx* ctx, int n, const bn256_bases* G, const bn256_bases* H, const uint8_t U[64], const uint8_t g[64],
+             const uint8_t h[64], const uint8_t v_be[32], const uint8_t prv_be[32], uint8_t* out, size_t cap,
+             size_t* out_len);
+int bp_verify(bn256_ctx* ctx, int n, const bn256_bases* G, const bn256_bases* H, const uint8_t U[64], const uint8_t g[64],
+              const uint8_t h[64], const uint8_t* proof, size_t len);
+
+/* ---- TEST HARNESS ONLY: the *_det entry points -----------------------------------------------------
+ * A 64-bit SplitMix64 seed stands in for rand.Reader so that transcripts can be compared byte for byte
+ * with the oracle's.  The seed generates the generators as k_i*G0 (known discrete logarithms: not
+ * sound) and every blinding value (a 2^64 search space: not hiding), and the verifier is handed the
+ * same seed.  Never a product path; use bp_setup / bp_prove / bp_verify above.
+ *
+ * NewBulletProofPublic(n) from the seeded reader, prv := next rand.Int, then
  * (*BulletProofPublic).Prove(v, prv) -- go/bp/main.go:27-34, :81-178, go/bp/main_test.go:16-36.
  * Wire format of the proof (the reference defines none; BulletProof struct go/bp/main.go:59-78):
  *   V, A, S, T1, T2 (64 B each) | tx, taux, nu (32 B BE each) | u32 BE k | L[k], R[k] (64 B each) | a, b (32 B) */

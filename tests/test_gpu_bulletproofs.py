@@ -216,3 +216,45 @@ def test_ac_protocol_wrong_witness_fails_like_the_oracle(ac):
     got = ac.run(0xAC00, pre, post, pub, prv)
     assert got["check_CT"] == want["check_CT"] and got["wnla_ok"] == want["wnla_ok"] and not got["wnla_ok"]
     assert got["CT"] == ref.marshal(want["CT"]).hex() and got["Co"] == ref.marshal(want["Co"]).hex()
+
+
+def test_product_entry_points_os_randomness_round_trip(eng):
+    """bp_setup / bp_prove / bp_verify: generators and blinding from the OS CSPRNG as the reference draws
+    them from crypto/rand (go/bp/util.go:51-63,81-90), nothing from a seed.  Proofs are randomised, so the
+    bar is prove -> verify: by the library, and by the oracle's restatement of Verify
+    (go/bp/main.go:181-249) over the downloaded generators."""
+    import secrets
+    import bn256_ref as ref
+    from crypto_amd import bp
+    n, v = 64, 11                                          # go/bp/main_test.go:16-36
+    pub = bp.BulletProofPublic(eng, n)
+    pub2 = bp.BulletProofPublic(eng, n)
+    assert pub.G.download() != pub2.G.download() and pub.U != pub2.U     # fresh generators every time
+    assert len(set(pub.G.download() + pub.H.download() + [pub.U, pub.g, pub.h])) == 2 * n + 3
+    prv = secrets.randbelow(ref.N)
+    p1, p2 = pub.prove(v, prv), pub.prove(v, prv)
+    assert p1 != p2 and p1[:64] == p2[:64]                 # fresh blinding; V = com(v, prv) is the same
+    assert pub.verify(p1) is None and pub.verify(p2) is None
+    assert pub2.verify(p1) is not None                     # other generators
+    bad = bytearray(p1)
+    bad[64 * 5 + 31] ^= 1                                  # tx
+    assert pub.verify(bytes(bad)) == "failed: tx ?= t0 + t1*x +t2*x^2"
+    # the oracle's Verify over the same public parameters
+    k = int.from_bytes(p1[64 * 5 + 96:64 * 5 + 100], "big")
+    pts = lambda off, m: [ref.unmarshal(p1[off + 64 * i:off + 64 * i + 64]) for i in range(m)]  # noqa: E731
+    sc = lambda off: int.from_bytes(p1[off:off + 32], "big")  # noqa: E731
+    V, A, S, T1, T2 = pts(0, 5)
+    o = 320
+    pr = {"V": V, "A": A, "S": S, "T1": T1, "T2": T2, "tx": sc(o), "taux": sc(o + 32), "nu": sc(o + 64),
+          "L": pts(o + 100, k), "R": pts(o + 100 + 64 * k, k), "a": sc(o + 100 + 128 * k), "b": sc(o + 132 + 128 * k)}
+    inner = ref.InnerArgumentPublic(n, [ref.unmarshal(p) for p in pub.G.download()],
+                                    [ref.unmarshal(p) for p in pub.H.download()], ref.unmarshal(pub.U))
+    opub = ref.BulletProofPublic(inner, n, ref.unmarshal(pub.g), ref.unmarshal(pub.h))
+    assert ref.bp_verify(opub, pr) is None
+    # a value outside the range does not verify (v = 2^64 needs 65 bits)
+    assert pub.verify(pub.prove(1 << 64, prv)) is not None
+    # the caller's own generators (uploaded handles) instead of bp_setup's
+    pub3 = bp.BulletProofPublic(eng, n, G=pub.G, H=pub.H, U=pub.U, g=pub.g, h=pub.h)
+    assert pub3.verify(p1) is None
+    with pytest.raises(RuntimeError, match="invalid length"):
+        bp.BulletProofPublic(eng, 32, G=pub.G, H=pub.H, U=pub.U, g=pub.g, h=pub.h).prove(v, prv)

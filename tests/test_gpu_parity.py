@@ -563,3 +563,53 @@ def test_submit_wait_chunked_2_22(eng, orc):
     finally:
         h.free()
         v.free()
+
+
+def test_inner_product_h_walkthrough(eng, orc):
+    """InnerProductH (go/bp/util.go:15-27) on the reference's own inputs, TestInnerArgumentProof
+    (go/bp/docs_test.go:381-430): a = [4,5,10,1], b = [2,1,2,10]; L, R, P and pcheck against the oracle's
+    restatement, and the identity the walkthrough checks with bytes.Equal: x^2 L + P + x^-2 R == pcheck."""
+    import bn256_ref as ref
+    n, n1 = 4, 2
+    graw = orc.synth_bases(0xA6, 2 * n + 1)
+    pts = [graw[64 * i:64 * i + 64] for i in range(2 * n + 1)]
+    g_raw, h_raw, u_raw = pts[:n], pts[n:2 * n], pts[2 * n]
+    g_ref, h_ref, u_ref = [ref.unmarshal(p) for p in g_raw], [ref.unmarshal(p) for p in h_raw], ref.unmarshal(u_raw)
+    G, H = eng.upload(g_raw), eng.upload(h_raw)
+    a, b = [4, 5, 10, 1], [2, 1, 2, 10]
+    z = [0] * n1
+    N = ref.N
+    vm = lambda x, y: sum(p * q for p, q in zip(x, y)) % N  # noqa: E731  vectorMul
+    c = vm(a, b)
+    assert c == 43  # the reference's comment says 39 (go/bp/docs_test.go:392); vectorMul gives 8 + 5 + 20 + 10
+
+    def both(*args):
+        got = eng.inner_product_h(n, G, H, u_raw, *args)
+        assert got == ref.marshal(ref.inner_product_h(n, g_ref, h_ref, u_ref, *args))
+        return got
+
+    L = both(z, a[:n1], b[n1:], z, vm(a[:n1], b[n1:]))
+    R = both(a[n1:], z, z, b[:n1], vm(a[n1:], b[:n1]))
+    P = both(a[:n1], a[n1:], b[:n1], b[n1:], c)
+    x = int.from_bytes(orc.synth_scalars(0xA7, 1), "big")
+    xinv = pow(x, -1, N)
+    a1 = [(p * x + q * xinv) % N for p, q in zip(a[:n1], a[n1:])]
+    b1 = [(p * x + q * xinv) % N for p, q in zip(b[n1:], b[:n1])]
+    sm = lambda v, k: [(e * k) % N for e in v]  # noqa: E731  vectorMulOnScalar
+    pcheck = both(sm(a1, xinv), sm(a1, x), sm(b1, x), sm(b1, xinv), vm(a1, b1))
+    x2 = x * x % N
+    U1 = eng.upload([L, P, R])  # x^2 L + P + x^-2 R through the device as well
+    assert eng.msm(U1, [x2, 1, pow(x2, -1, N)]) == pcheck
+    # the reference's panics
+    with pytest.raises(ValueError, match="invalid n"):
+        eng.inner_product_h(3, G, H, u_raw, z, z, z, z, 0)
+    with pytest.raises(ValueError, match="invalid length for scalar mul"):
+        eng.inner_product_h(n, G, H, u_raw, a, a[n1:], b[:n1], b[n1:], c)
+    # a larger even n, random scalars, U as a resident handle
+    n = 64
+    graw = orc.synth_bases(0xA8, 2 * n + 1)
+    sraw = orc.synth_scalars(0xA9, 2 * n + 1)
+    sc = [int.from_bytes(sraw[32 * i:32 * i + 32], "big") for i in range(2 * n + 1)]
+    G2, H2, U2 = eng.upload(graw[:64 * n]), eng.upload(graw[64 * n:128 * n]), eng.upload(graw[128 * n:])
+    got = eng.inner_product_h(n, G2, H2, U2, sc[:32], sc[32:64], sc[64:96], sc[96:128], sc[128])
+    assert got == orc.msm(graw, sraw)

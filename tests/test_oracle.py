@@ -282,3 +282,10 @@ def test_curve_is_determined_by_the_group_order_the_reference_pins():
                 break
         # generic affine ladder on y^2 = x^3 + b (the doubling formula does not involve b)
         assert ref.mul_affine_slow(n, (x, y)) is not ref.INF
+
+
+def test_vector_mul_on_matrix_reference_answer():
+    """go/bppp/util_test.go:166-174: a * m = [10*1 + 5*3, 10*2 + 5*4] = [25, 40]."""
+    import bn256_ref as ref
+    assert ref.vector_mul_on_matrix([10, 5], [[1, 2], [3, 4]]) == [25, 40]
+    assert ref.matrix_mul_on_vector([10, 5], [[1, 2], [3, 4]]) == [20, 50]  # rows: go/bppp/util.go:311-319
