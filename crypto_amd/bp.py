@@ -8,7 +8,8 @@ from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPAMD_LIB") or os.path.join(_HERE, "libbpamd.so")  # override: A/B builds
-EXPORTS = ["bp_setup", "bp_prove", "bp_verify", "bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
+EXPORTS = ["bp_schnorr_msg", "bp_schnorr_multisig", "bp_schnorr_sign_det", "bp_schnorr_verify_batch",
+           "bp_veca_encrypt_det", "bp_veca_verify", "bp_veca_decrypt", "bp_setup", "bp_prove", "bp_verify", "bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
            "bp_wnla_det", "bp_wnla_synthetic", "bp_ac_det"]
 _bp = None
 
@@ -40,6 +41,14 @@ def load() -> C.CDLL:
     lib.bp_wnla_synthetic.argtypes = [vp, C.c_uint64, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int)]
     lib.bp_ac_det.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(AcCircuit), C.c_char_p, sz, C.POINTER(sz)]
+    cp = C.c_char_p
+    lib.bp_schnorr_msg.argtypes = [cp, sz, cp]
+    lib.bp_schnorr_multisig.argtypes = [cp, cp, cp, cp, cp, cp]
+    lib.bp_schnorr_sign_det.argtypes = [vp, C.c_uint64, cp, cp, cp, cp, cp, cp]
+    lib.bp_schnorr_verify_batch.argtypes = [vp, sz, cp, cp, cp, cp, cp, cp]
+    lib.bp_veca_encrypt_det.argtypes = [vp, C.c_uint64, cp, cp, cp, cp, cp, cp, cp, cp]
+    lib.bp_veca_verify.argtypes = [vp, cp, cp, cp, cp, cp]
+    lib.bp_veca_decrypt.argtypes = [cp, cp, cp, cp, cp, cp, cp]
     lib.bp_keccak256.argtypes = [C.c_char_p, sz, C.c_char_p]
     lib.bp_last_error.restype = C.c_char_p
     _bp = lib
@@ -244,3 +253,77 @@ def parse_proof(raw: bytes) -> dict:
     out["b"] = int.from_bytes(raw[pos + 32:pos + 64], "big")
     assert pos + 64 == len(raw)
     return out
+
+
+def _b32(x: int) -> bytes:
+    return int(x).to_bytes(32, "big")
+
+
+class Schnorr:
+    """go/schnorr-bn256/schnorr.go over libbpamd: Msg, MultiSigSchnorr, SignSchnorr (seeded r),
+    VerifySchnorr batched on the device.  Points are Marshal() bytes, S the reference's unreduced int."""
+
+    def __init__(self, engine):
+        self.eng, self.lib = engine, load()
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} rc={rc}: {self.lib.bp_last_error().decode()}")
+
+    def msg(self, *chunks: bytes) -> int:
+        data = b"".join(chunks)
+        out = C.create_string_buffer(32)
+        self._chk(self.lib.bp_schnorr_msg(data, len(data), out), "bp_schnorr_msg")
+        return int.from_bytes(out.raw, "big")
+
+    def multisig(self, prv: int, r: int, pub_common: bytes, r_common: bytes, m: int) -> tuple:
+        out = C.create_string_buffer(64)
+        self._chk(self.lib.bp_schnorr_multisig(_b32(prv), _b32(r), pub_common, r_common, _b32(m), out), "bp_schnorr_multisig")
+        return r_common, int.from_bytes(out.raw, "big")
+
+    def sign(self, prv: int, pub: bytes, G: bytes, m: int, seed: int) -> tuple:
+        R, S = C.create_string_buffer(64), C.create_string_buffer(64)
+        self._chk(self.lib.bp_schnorr_sign_det(self.eng.ctx, seed, _b32(prv), pub, G, _b32(m), R, S), "bp_schnorr_sign_det")
+        return R.raw, int.from_bytes(S.raw, "big")
+
+    def verify_batch(self, sigs, pubs, G: bytes, ms) -> list:
+        n = len(sigs)
+        ok = C.create_string_buffer(max(n, 1))
+        self._chk(self.lib.bp_schnorr_verify_batch(
+            self.eng.ctx, n, b"".join(s[0] for s in sigs), b"".join(int(s[1]).to_bytes(64, "big") for s in sigs),
+            b"".join(pubs), G, b"".join(_b32(m) for m in ms), ok), "bp_schnorr_verify_batch")
+        return [bool(ok.raw[i]) for i in range(n)]
+
+    def verify(self, sig, pub: bytes, G: bytes, m: int) -> bool:
+        return self.verify_batch([sig], [pub], G, [m])[0]
+
+
+class VeCa:
+    """go/ve-ca/main.go over libbpamd: Encrypt (seeded reader), Verify, Decrypt; proofs as the byte string
+    described in include/bp_amd.h."""
+    K = 128
+    PROOF_BYTES = 10 * 128 * 32 + 128 * 64
+
+    def __init__(self, engine):
+        self.eng, self.lib = engine, load()
+
+    def encrypt(self, v: int, r: int, s_r: int, g: int, GenG: bytes, GenH: bytes, seed: int) -> tuple:
+        proof, Cc = C.create_string_buffer(self.PROOF_BYTES), C.create_string_buffer(64)
+        rc = self.lib.bp_veca_encrypt_det(self.eng.ctx, seed, _b32(v), _b32(r), _b32(s_r), _b32(g), GenG, GenH, proof, Cc)
+        if rc:
+            raise RuntimeError(f"bp_veca_encrypt_det rc={rc}: {self.lib.bp_last_error().decode()}")
+        return proof.raw, Cc.raw
+
+    def verify(self, proof: bytes, s_r: int, Cc: bytes, GenG: bytes, GenH: bytes) -> str | None:
+        """None when Verify returns true, else the message the reference prints."""
+        if len(proof) != self.PROOF_BYTES:
+            raise ValueError("proof length")
+        rc = self.lib.bp_veca_verify(self.eng.ctx, proof, _b32(s_r), Cc, GenG, GenH)
+        return None if rc == 0 else self.lib.bp_last_error().decode()
+
+    def decrypt(self, u: int, proof: bytes, Cc: bytes, GenG: bytes, GenH: bytes) -> tuple:
+        v, r = C.create_string_buffer(32), C.create_string_buffer(32)
+        rc = self.lib.bp_veca_decrypt(_b32(u), proof, Cc, GenG, GenH, v, r)
+        if rc:
+            raise RuntimeError(self.lib.bp_last_error().decode())
+        return int.from_bytes(v.raw, "big"), int.from_bytes(r.raw, "big")

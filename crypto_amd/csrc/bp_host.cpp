@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -1670,6 +1671,395 @@ extern "C" int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_
   } catch (const std::exception& e) {
     g_err = e.what();
     if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
+    return BP_EFAIL;
+  }
+}
+
+// ============================================================================ SURVEY 8f rank 4
+// go/schnorr-bn256 (schnorr.go) and go/ve-ca (main.go, types.go, enc.go) over the same ABI.  Their
+// vector work is what the device does: k = 128 independent two-term commitments (bn256_com_batch),
+// batches of hash_i * PublicKey_i + R_i and S_i * G (bn256_scalar_mul_batch, bn256_add_batch);
+// hashes, the XOR cipher and the modular exponentiations stay on the host as they are scalar work.
+namespace {
+typedef std::vector<uint8_t> ByteVec;
+void appendBig(ByteVec& o, const uint8_t be[32]) {  // big.Int.Bytes(): minimal big-endian, empty for 0
+  size_t i = 0;
+  while (i < 32 && be[i] == 0) i++;
+  o.insert(o.end(), be + i, be + 32);
+}
+void appendFr(ByteVec& o, const Fr& a) {  // FBytes, go/ve-ca/types.go:69-71
+  uint8_t b[32];
+  fr_to_be(b, a);
+  appendBig(o, b);
+}
+Fr hashModOrder(const ByteVec& data) {  // Keccak256(...) mod Order: Msg (schnorr.go:26-28), Hash (ve-ca/types.go:93-96)
+  uint8_t d[32];
+  keccak256(d, data);
+  return fr_from_be(d);
+}
+Fr frPow(const Fr& base, const Fr& e) {  // FPow: new(big.Int).Exp(f1, f2, Order), go/ve-ca/types.go:65-67
+  uint64_t w[4];
+  fr_to_raw(w, e);
+  Fr acc = kFrOne;
+  for (int i = 255; i >= 0; i--) {
+    acc = mul(acc, acc);
+    if ((w[i >> 6] >> (i & 63)) & 1) acc = mul(acc, base);
+  }
+  return acc;
+}
+// hash := Msg(m.Bytes(), PublicKey.Marshal(), R.Marshal()), schnorr.go:33,50,70
+Fr schnorrChallenge(const uint8_t m_be[32], const uint8_t pub[64], const uint8_t R[64]) {
+  ByteVec d;
+  appendBig(d, m_be);
+  d.insert(d.end(), pub, pub + 64);
+  d.insert(d.end(), R, R + 64);
+  return hashModOrder(d);
+}
+// s = r + hash * prv as the reference leaves it: a plain big.Int sum, NOT reduced (schnorr.go:34,52)
+void schnorrS(uint8_t S_be[64], const Fr& r, const Fr& hash, const Fr& prv) {
+  uint64_t a[4], b[4], c[4], t[9] = {0};
+  fr_to_raw(a, hash);
+  fr_to_raw(b, prv);
+  fr_to_raw(c, r);
+  for (int i = 0; i < 4; i++) {
+    uint64_t carry = 0;
+    for (int j = 0; j < 4; j++) {
+      u128 cur = (u128)a[i] * b[j] + t[i + j] + carry;
+      t[i + j] = (uint64_t)cur;
+      carry = (uint64_t)(cur >> 64);
+    }
+    t[i + 4] = carry;
+  }
+  u128 cy = 0;
+  for (int i = 0; i < 8; i++) {
+    cy += (u128)t[i] + (i < 4 ? c[i] : 0);
+    t[i] = (uint64_t)cy;
+    cy >>= 64;
+  }
+  for (int i = 0; i < 8; i++)
+    for (int k = 0; k < 8; k++) S_be[(7 - i) * 8 + k] = (uint8_t)(t[i] >> (56 - 8 * k));
+}
+Fr frFromBe64(const uint8_t be[64]) {  // a 512-bit integer mod Order
+  const Fr two256 = fr_from_raw(kFrOne.l);  // the raw words of Montgomery 1 are 2^256 mod n
+  return add(mul(fr_from_be(be), two256), fr_from_be(be + 32));
+}
+
+constexpr int kVecaK = BP_VECA_K;
+struct VecaProof {  // Proof, go/ve-ca/main.go:10-16; E holds XOR results, which may exceed Order: raw bytes
+  uint8_t E[4][kVecaK][32];
+  Fr Alpha[2][kVecaK], P[2][kVecaK], Share[2][kVecaK];
+  Point X[kVecaK];
+};
+void vecaSerialize(uint8_t* o, const VecaProof& p) {
+  for (int t = 0; t < 4; t++)
+    for (int i = 0; i < kVecaK; i++, o += 32) memcpy(o, p.E[t][i], 32);
+  for (auto rows : {p.Alpha, p.P, p.Share})
+    for (int t = 0; t < 2; t++)
+      for (int i = 0; i < kVecaK; i++, o += 32) fr_to_be(o, rows[t][i]);
+  for (int i = 0; i < kVecaK; i++, o += 64) memcpy(o, p.X[i].b, 64);
+}
+bool vecaDeserialize(VecaProof& p, const uint8_t* in) {
+  for (int t = 0; t < 4; t++)
+    for (int i = 0; i < kVecaK; i++, in += 32) memcpy(p.E[t][i], in, 32);
+  for (auto rows : {p.Alpha, p.P, p.Share})
+    for (int t = 0; t < 2; t++)
+      for (int i = 0; i < kVecaK; i++, in += 32) {
+        uint64_t w[4];
+        hostg1::be_load(w, in);
+        if (geq_n(w)) return false;
+        rows[t][i] = fr_from_raw(w);
+      }
+  for (int i = 0; i < kVecaK; i++, in += 64) {
+    memcpy(p.X[i].b, in, 64);
+    hostg1::Pt t;
+    if (hostg1::unmarshal(t, p.X[i].b)) return false;
+  }
+  return true;
+}
+// E / D, go/ve-ca/enc.go:7-45: XOR of the 32-byte big-endian paddings
+void vecaXor(uint8_t out[32], const Fr& key, const uint8_t val[32]) {
+  uint8_t k[32];
+  fr_to_be(k, key);
+  for (int i = 0; i < 32; i++) out[i] = k[i] ^ val[i];
+}
+// rho0, rho1 (main.go:44-49, :95-98) and c (main.go:66-73, :100)
+void vecaChallenges(const Point& GenG, const Point& GenH, const Point& C, const VecaProof& p, Fr rho[2], uint8_t c_be[32]) {
+  ByteVec pre;
+  pre.insert(pre.end(), GenG.b, GenG.b + 64);
+  pre.insert(pre.end(), GenH.b, GenH.b + 64);
+  pre.insert(pre.end(), C.b, C.b + 64);
+  for (int i = 0; i < kVecaK; i++) pre.insert(pre.end(), p.X[i].b, p.X[i].b + 64);
+  for (int b = 0; b < 2; b++) {
+    ByteVec d = pre;
+    d.push_back((uint8_t)b);
+    rho[b] = hashModOrder(d);
+  }
+  ByteVec d;
+  appendFr(d, rho[0]);
+  appendFr(d, rho[1]);
+  for (int t = 0; t < 4; t++)
+    for (int i = 0; i < kVecaK; i++) appendBig(d, p.E[t][i]);
+  fr_to_be(c_be, hashModOrder(d));
+}
+inline int bitOf(const uint8_t be[32], int pos) { return (be[31 - pos / 8] >> (pos % 8)) & 1; }  // FBit
+// [a_i * GenH + b_i * GenG] on the device: X[i] of Encrypt (main.go:37-40) and the first two terms of
+// Verify's X (main.go:104-107)
+std::vector<Point> vecaComBatch(bn256_ctx* ctx, const Point& GenG, const Point& GenH, const Fr* a, const Fr* b, size_t n,
+                                const std::vector<Point>* plus = nullptr) {
+  ByteVec ab(32 * n), bb(32 * n);
+  for (size_t i = 0; i < n; i++) {
+    fr_to_be(&ab[32 * i], a[i]);
+    fr_to_be(&bb[32 * i], b[i]);
+  }
+  bn256_bases* h = nullptr;
+  chk(bn256_com_batch(ctx, GenH.b, GenG.b, ab.data(), bb.data(), n, &h));
+  DevPoints sum(ctx, h);
+  if (plus) {  // + rho[b_i] * C, a per-element choice between two points (main.go:108)
+    ByteVec raw(64 * n);
+    for (size_t i = 0; i < n; i++) memcpy(&raw[64 * i], (*plus)[i].b, 64);
+    bn256_bases *ph = nullptr, *oh = nullptr;
+    chk(bn256_bases_upload(ctx, raw.data(), n, 0, &ph));
+    DevPoints pl(ctx, ph);
+    chk(bn256_add_batch(ctx, sum.h, 0, pl.h, 0, n, &oh));
+    sum = DevPoints(ctx, oh);
+  }
+  ByteVec out(64 * n);
+  chk(bn256_bases_download(ctx, sum.h, 0, n, out.data()));
+  std::vector<Point> r(n);
+  for (size_t i = 0; i < n; i++) memcpy(r[i].b, &out[64 * i], 64);
+  return r;
+}
+Point pointFrom(const uint8_t b[64]) {
+  Point p;
+  memcpy(p.b, b, 64);
+  pt_load(p);  // throws on a malformed point, like Unmarshal
+  return p;
+}
+}  // namespace
+
+extern "C" int bp_schnorr_msg(const uint8_t* data, size_t len, uint8_t m_be[32]) {
+  if ((!data && len) || !m_be) return BN256_EINVAL;
+  ByteVec d(data, data + len);
+  fr_to_be(m_be, hashModOrder(d));
+  return 0;
+}
+
+extern "C" int bp_schnorr_multisig(const uint8_t prv_be[32], const uint8_t r_be[32], const uint8_t pub_common[64],
+                                   const uint8_t r_common[64], const uint8_t m_be[32], uint8_t S_be[64]) {
+  try {
+    if (!prv_be || !r_be || !pub_common || !r_common || !m_be || !S_be) return BN256_EINVAL;
+    pointFrom(pub_common);
+    pointFrom(r_common);
+    schnorrS(S_be, fr_from_be(r_be), schnorrChallenge(m_be, pub_common, r_common), fr_from_be(prv_be));
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return BP_EFAIL;
+  }
+}
+
+extern "C" int bp_schnorr_sign_det(bn256_ctx* ctx, uint64_t seed, const uint8_t prv_be[32], const uint8_t pub[64],
+                                   const uint8_t G[64], const uint8_t m_be[32], uint8_t R_out[64], uint8_t S_be[64]) {
+  try {
+    if (!ctx || !prv_be || !pub || !G || !m_be || !R_out || !S_be) return BN256_EINVAL;
+    pointFrom(pub);
+    ByteStream rd{seed};
+    uint8_t rb[32];
+    Fr r = rd.randInt(rb);  // R(G), schnorr.go:17-24: rand.Int, then r*G -- on the device, through the ABI
+    bn256_bases *g = nullptr, *rg = nullptr;
+    chk(bn256_bases_upload(ctx, G, 1, 0, &g));
+    DevPoints dg(ctx, g);
+    chk(bn256_scalar_mul_batch(ctx, g, 0, 1, rb, 0, &rg));
+    DevPoints dr(ctx, rg);
+    Point R = dr.at(0);
+    memcpy(R_out, R.b, 64);
+    schnorrS(S_be, r, schnorrChallenge(m_be, pub, R.b), fr_from_be(prv_be));
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
+    return BP_EFAIL;
+  }
+}
+
+extern "C" int bp_schnorr_verify_batch(bn256_ctx* ctx, size_t n, const uint8_t* R, const uint8_t* S_be, const uint8_t* pub,
+                                       const uint8_t G[64], const uint8_t* m_be, uint8_t* ok) {
+  try {
+    if (!ctx || !G || (n && (!R || !S_be || !pub || !m_be || !ok))) return BN256_EINVAL;
+    if (!n) return 0;
+    // p1_i = hash_i * PublicKey_i + R_i ; p2_i = S_i * G ; bytes.Equal(p1.Marshal(), p2.Marshal())   (schnorr.go:70-78)
+    ByteVec hb(32 * n), sb(32 * n), zero(32 * n, 0);
+    for (size_t i = 0; i < n; i++) {
+      fr_to_be(&hb[32 * i], schnorrChallenge(m_be + 32 * i, pub + 64 * i, R + 64 * i));
+      fr_to_be(&sb[32 * i], frFromBe64(S_be + 64 * i));  // k*G = (k mod Order)*G
+    }
+    bn256_bases *hp = nullptr, *hr = nullptr, *t = nullptr, *p1 = nullptr, *p2 = nullptr;
+    chk(bn256_bases_upload(ctx, pub, n, 0, &hp));
+    DevPoints dp(ctx, hp);
+    chk(bn256_bases_upload(ctx, R, n, 0, &hr));
+    DevPoints drr(ctx, hr);
+    chk(bn256_scalar_mul_batch(ctx, hp, 0, n, hb.data(), 0, &t));
+    DevPoints dt(ctx, t);
+    chk(bn256_add_batch(ctx, t, 0, hr, 0, n, &p1));
+    DevPoints d1(ctx, p1);
+    chk(bn256_com_batch(ctx, G, G, sb.data(), zero.data(), n, &p2));
+    DevPoints d2(ctx, p2);
+    ByteVec a(64 * n), b(64 * n);
+    chk(bn256_bases_download(ctx, p1, 0, n, a.data()));
+    chk(bn256_bases_download(ctx, p2, 0, n, b.data()));
+    for (size_t i = 0; i < n; i++) ok[i] = memcmp(&a[64 * i], &b[64 * i], 64) == 0;
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
+    return BP_EFAIL;
+  }
+}
+
+// Encrypt, go/ve-ca/main.go:18-92, with the reader injected (draw order: p[0..3][k], x[0..1][k])
+extern "C" int bp_veca_encrypt_det(bn256_ctx* ctx, uint64_t seed, const uint8_t v_be[32], const uint8_t r_be[32],
+                                   const uint8_t s_r_be[32], const uint8_t g_be[32], const uint8_t GenG_[64],
+                                   const uint8_t GenH_[64], uint8_t* proof_out, uint8_t C_out[64]) {
+  try {
+    if (!ctx || !v_be || !r_be || !s_r_be || !g_be || !GenG_ || !GenH_ || !proof_out || !C_out) return BN256_EINVAL;
+    const Point GenG = pointFrom(GenG_), GenH = pointFrom(GenH_);
+    const Fr v = fr_from_be(v_be), r = fr_from_be(r_be), s_r = fr_from_be(s_r_be), g = fr_from_be(g_be);
+    ByteStream rd{seed};
+    std::vector<FrVec> p(4), x(2);
+    for (auto& row : p) row = rd.values(kVecaK);
+    for (auto& row : x) row = rd.values(kVecaK);
+    auto pr = std::make_unique<VecaProof>();
+    std::vector<Point> X = vecaComBatch(ctx, GenG, GenH, x[0].data(), x[1].data(), kVecaK);
+    for (int i = 0; i < kVecaK; i++) pr->X[i] = X[i];
+    const Point C = com(GenH, GenG, v, r);  // GAdd(GMul(v, GenH), GMul(r, GenG)), main.go:42
+    Fr alpha[4][kVecaK];
+    {
+      // rho needs only X and C; E is filled afterwards
+      VecaProof& q = *pr;
+      memset(q.E, 0, sizeof q.E);
+      Fr rho[2];
+      uint8_t c_unused[32];
+      vecaChallenges(GenG, GenH, C, q, rho, c_unused);
+      for (int i = 0; i < kVecaK; i++) {
+        alpha[0][i] = sub(x[0][i], mul(rho[0], v));
+        alpha[1][i] = sub(x[0][i], mul(rho[1], v));
+        alpha[2][i] = sub(x[1][i], mul(rho[0], r));
+        alpha[3][i] = sub(x[1][i], mul(rho[1], r));
+        for (int t = 0; t < 4; t++) {
+          uint8_t ab[32];
+          fr_to_be(ab, alpha[t][i]);
+          vecaXor(q.E[t][i], frPow(s_r, p[t][i]), ab);  // e = E(s, alpha), s = FPow(s_r, p)
+        }
+      }
+      uint8_t c_be[32];
+      vecaChallenges(GenG, GenH, C, q, rho, c_be);
+      for (int i = 0; i < kVecaK; i++) {
+        const int b = bitOf(c_be, i), d = 1 - b;
+        q.Alpha[0][i] = alpha[b][i];
+        q.Alpha[1][i] = alpha[b + 2][i];
+        q.P[0][i] = p[b][i];
+        q.P[1][i] = p[b + 2][i];
+        q.Share[0][i] = frPow(g, p[d][i]);
+        q.Share[1][i] = frPow(g, p[d + 2][i]);
+      }
+    }
+    vecaSerialize(proof_out, *pr);
+    memcpy(C_out, C.b, 64);
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
+    return BP_EFAIL;
+  }
+}
+
+// Verify, go/ve-ca/main.go:94-133: 0 = true, BP_EVERIFY = false with the message the reference prints
+extern "C" int bp_veca_verify(bn256_ctx* ctx, const uint8_t* proof, const uint8_t s_r_be[32], const uint8_t C_[64],
+                              const uint8_t GenG_[64], const uint8_t GenH_[64]) {
+  try {
+    if (!ctx || !proof || !s_r_be || !C_ || !GenG_ || !GenH_) return BN256_EINVAL;
+    const Point GenG = pointFrom(GenG_), GenH = pointFrom(GenH_), C = pointFrom(C_);
+    const Fr s_r = fr_from_be(s_r_be);
+    auto pr = std::make_unique<VecaProof>();
+    if (!vecaDeserialize(*pr, proof)) {
+      g_err = "malformed proof encoding";
+      return BP_EFAIL;
+    }
+    Fr rho[2];
+    uint8_t c_be[32];
+    vecaChallenges(GenG, GenH, C, *pr, rho, c_be);
+    // the k sigma answers as one batch: alpha0_i * GenH + alpha1_i * GenG on the device, + rho[b_i] * C
+    const Point rc[2] = {scalarMult(C, rho[0]), scalarMult(C, rho[1])};
+    std::vector<Point> plus(kVecaK);
+    for (int i = 0; i < kVecaK; i++) plus[i] = rc[bitOf(c_be, i)];
+    std::vector<Point> X = vecaComBatch(ctx, GenG, GenH, pr->Alpha[0], pr->Alpha[1], kVecaK, &plus);
+    for (int i = 0; i < kVecaK; i++) {  // the reference checks sigma, e0, e1 per i, in this order
+      const int b = bitOf(c_be, i);
+      if (!pointEq(X[i], pr->X[i])) {
+        g_err = "invalid sigma answer";
+        return BP_EVERIFY;
+      }
+      uint8_t a0[32], a1[32], e0[32], e1[32];
+      fr_to_be(a0, pr->Alpha[0][i]);
+      fr_to_be(a1, pr->Alpha[1][i]);
+      vecaXor(e0, frPow(s_r, pr->P[0][i]), a0);
+      vecaXor(e1, frPow(s_r, pr->P[1][i]), a1);
+      if (memcmp(e0, pr->E[b][i], 32) != 0) {
+        g_err = "invalid e0 answer";
+        return BP_EVERIFY;
+      }
+      if (memcmp(e1, pr->E[b + 2][i], 32) != 0) {
+        g_err = "invalid e1 answer";
+        return BP_EVERIFY;
+      }
+    }
+    g_err.clear();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    if (ctx) (void)bn256_ctx_drain(ctx);
+    return BP_EFAIL;
+  }
+}
+
+// Decrypt, go/ve-ca/main.go:135-174 (scalar work and one two-term commitment per attempt: host only)
+extern "C" int bp_veca_decrypt(const uint8_t u_be[32], const uint8_t* proof, const uint8_t C_[64], const uint8_t GenG_[64],
+                               const uint8_t GenH_[64], uint8_t v_out[32], uint8_t r_out[32]) {
+  try {
+    if (!u_be || !proof || !C_ || !GenG_ || !GenH_ || !v_out || !r_out) return BN256_EINVAL;
+    const Point GenG = pointFrom(GenG_), GenH = pointFrom(GenH_), C = pointFrom(C_);
+    const Fr u = fr_from_be(u_be);
+    auto pr = std::make_unique<VecaProof>();
+    if (!vecaDeserialize(*pr, proof)) {
+      g_err = "malformed proof encoding";
+      return BP_EFAIL;
+    }
+    Fr rho[2];
+    uint8_t c_be[32];
+    vecaChallenges(GenG, GenH, C, *pr, rho, c_be);
+    for (int i = 0; i < kVecaK; i++) {
+      const int b = bitOf(c_be, i), d = 1 - b;
+      uint8_t a0[32], a1[32];
+      vecaXor(a0, frPow(pr->Share[0][i], u), pr->E[d][i]);      // D(keyV, E[d][i])
+      vecaXor(a1, frPow(pr->Share[1][i], u), pr->E[d + 2][i]);
+      const Fr den = fr_inv(sub(rho[b], rho[d]));
+      const Fr v = mul(sub(fr_from_be(a0), pr->Alpha[0][i]), den);
+      const Fr r = mul(sub(fr_from_be(a1), pr->Alpha[1][i]), den);
+      if (pointEq(com(GenH, GenG, v, r), C)) {
+        fr_to_be(v_out, v);
+        fr_to_be(r_out, r);
+        g_err.clear();
+        return 0;
+      }
+    }
+    g_err = "Failed to recover";
+    return BP_EVERIFY;
+  } catch (const std::exception& e) {
+    g_err = e.what();
     return BP_EFAIL;
   }
 }

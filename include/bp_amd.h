@@ -101,6 +101,43 @@ int bp_ac_det(bn256_ctx* ctx, uint64_t seed, int pre_draws, int post_draws, cons
 int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_t nn, double* ms_setup, double* ms_run,
                       int* rounds);
 
+/* ---- go/schnorr-bn256 -------------------------------------------------------
+ * Scalars are 32-byte big-endian; S is the reference's UNREDUCED big.Int r + hash * prv
+ * (schnorr.go:34,52), 64-byte big-endian; m is the *big.Int message (Msg's result or any scalar).
+ *   bp_schnorr_msg          Msg(bytes...), schnorr.go:26-28: Keccak256(data) mod Order.
+ *   bp_schnorr_multisig     MultiSigSchnorr, schnorr.go:32-40 (host arithmetic only).
+ *   bp_schnorr_sign_det     SignSchnorr, schnorr.go:44-59, with r from the seeded reader (R(G),
+ *                           schnorr.go:17-24; r * G runs on the device).  Test harness, like *_det above.
+ *   bp_schnorr_verify_batch VerifySchnorr, schnorr.go:64-79, over n signatures at once: the device
+ *                           computes hash_i * PublicKey_i + R_i and S_i * G, ok[i] = bytes.Equal. */
+int bp_schnorr_msg(const uint8_t* data, size_t len, uint8_t m_be[32]);
+int bp_schnorr_multisig(const uint8_t prv_be[32], const uint8_t r_be[32], const uint8_t pub_common[64],
+                        const uint8_t r_common[64], const uint8_t m_be[32], uint8_t S_be[64]);
+int bp_schnorr_sign_det(bn256_ctx* ctx, uint64_t seed, const uint8_t prv_be[32], const uint8_t pub[64], const uint8_t G[64],
+                        const uint8_t m_be[32], uint8_t R_out[64], uint8_t S_be[64]);
+int bp_schnorr_verify_batch(bn256_ctx* ctx, size_t n, const uint8_t* R, const uint8_t* S_be, const uint8_t* pub,
+                            const uint8_t G[64], const uint8_t* m_be, uint8_t* ok);
+
+/* ---- go/ve-ca: verifiable encryption by cut-and-choose, k = 128 ---------------
+ * Proof (go/ve-ca/main.go:10-16) on the wire (the reference defines no format): E[4][k] | Alpha[2][k] |
+ * P[2][k] | Share[2][k], 32-byte big-endian each, then X[k] as Marshal() bytes.
+ *   bp_veca_encrypt_det  Encrypt, main.go:18-92, reader injected; X[i] = x0[i]*GenH + x1[i]*GenG is one
+ *                        bn256_com_batch.  Test harness (seeded).
+ *   bp_veca_verify       Verify, main.go:94-133: the k sigma answers alpha0*GenH + alpha1*GenG + rho[b]*C
+ *                        are one bn256_com_batch + bn256_add_batch.  0 = true; BP_EVERIFY = false with the
+ *                        message the reference prints ("invalid sigma answer" / "invalid e0 answer" /
+ *                        "invalid e1 answer") in bp_last_error().
+ *   bp_veca_decrypt      Decrypt, main.go:135-174 (host only). */
+#define BP_VECA_K 128
+#define BP_VECA_PROOF_BYTES (10 * BP_VECA_K * 32 + BP_VECA_K * 64)
+int bp_veca_encrypt_det(bn256_ctx* ctx, uint64_t seed, const uint8_t v_be[32], const uint8_t r_be[32],
+                        const uint8_t s_r_be[32], const uint8_t g_be[32], const uint8_t GenG[64], const uint8_t GenH[64],
+                        uint8_t* proof_out, uint8_t C_out[64]);
+int bp_veca_verify(bn256_ctx* ctx, const uint8_t* proof, const uint8_t s_r_be[32], const uint8_t C[64],
+                   const uint8_t GenG[64], const uint8_t GenH[64]);
+int bp_veca_decrypt(const uint8_t u_be[32], const uint8_t* proof, const uint8_t C[64], const uint8_t GenG[64],
+                    const uint8_t GenH[64], uint8_t v_out[32], uint8_t r_out[32]);
+
 /* hash()'s digest function: legacy Keccak-256 -- go/bp/util.go:232. */
 int bp_keccak256(const uint8_t* msg, size_t len, uint8_t out[32]);
 

@@ -1062,3 +1062,148 @@ def ac_protocol(pub, prv, reader):
         ok, rounds, lf, nf = False, None, None, None
     return dict(V=V, Co=Co, Cl=Cl, Cr=Cr, V_=V_, Cs=Cs, PT=PT, CT=CT, check_V=check_V, check_CT=check_CT,
                 check_45=check_45, vT=vT, rs=rs, lT=lT, nT=nT, cT=cT, wnla_ok=ok, rounds=rounds, l=lf, n=nf)
+
+
+# --------------------------------------------------------------------------------------
+# go/schnorr-bn256.  Hash = go-ethereum crypto.Keccak256 = legacy Keccak-256
+# over the concatenation (go/schnorr-bn256/types.go:21).
+# --------------------------------------------------------------------------------------
+def big_bytes(x: int) -> bytes:
+    """big.Int.Bytes(): minimal big-endian, empty for 0."""
+    return x.to_bytes((x.bit_length() + 7) // 8, "big")
+
+
+def schnorr_r(reader, G):
+    """R(G), go/schnorr-bn256/schnorr.go:17-24: r <- rand.Int, (r, r*G)."""
+    r = rand_int(reader)
+    return r, mul(r, G)
+
+
+def schnorr_msg(*chunks: bytes) -> int:
+    """Msg, go/schnorr-bn256/schnorr.go:26-28."""
+    return int.from_bytes(keccak256(b"".join(chunks)), "big") % N
+
+
+def schnorr_multisig(prv: int, r: int, pub_common, r_common, m: int):
+    """MultiSigSchnorr, go/schnorr-bn256/schnorr.go:32-40.  s = r + hash*prv is NOT reduced there."""
+    h = schnorr_msg(big_bytes(m), marshal(pub_common), marshal(r_common))
+    return r_common, r + h * prv
+
+
+def schnorr_sign(prv: int, pub, G, m: int, reader):
+    """SignSchnorr, go/schnorr-bn256/schnorr.go:44-59."""
+    r, R = schnorr_r(reader, G)
+    return schnorr_multisig(prv, r, pub, R, m)
+
+
+def schnorr_verify(sig, pub, G, m: int) -> bool:
+    """VerifySchnorr, go/schnorr-bn256/schnorr.go:64-79."""
+    R, s = sig
+    h = schnorr_msg(big_bytes(m), marshal(pub), marshal(R))
+    p1 = add(mul(h, pub), R)
+    p2 = mul(s % N, G)          # k*G = (k mod n)*G
+    return marshal(p1) == marshal(p2)
+
+
+# --------------------------------------------------------------------------------------
+# go/ve-ca: verifiable encryption by cut-and-choose, k = 128 (go/ve-ca/main.go:8).  F = big.Int mod
+# Order, G = bn256.G1 (go/ve-ca/types.go); Hash = Keccak256Hash(...) mod Order (types.go:93-96);
+# FBytes = big.Int.Bytes() (minimal); E / D = XOR of the 32-byte paddings (go/ve-ca/enc.go).
+# --------------------------------------------------------------------------------------
+VECA_K = 128
+
+
+def veca_hash(*chunks: bytes) -> int:
+    return int.from_bytes(keccak256(b"".join(chunks)), "big") % N
+
+
+def veca_e(key: int, val: int) -> int:
+    """E (and D: the same XOR), go/ve-ca/enc.go:7-25.  The result may exceed Order."""
+    return int.from_bytes(bytes(a ^ b for a, b in zip(key.to_bytes(32, "big"), val.to_bytes(32, "big"))), "big")
+
+
+def _veca_rho(GenG, GenH, C, X):
+    pre = marshal(GenG) + marshal(GenH) + marshal(C) + b"".join(marshal(x) for x in X)
+    return veca_hash(pre, b"\x00"), veca_hash(pre, b"\x01")
+
+
+def _veca_c(rho0, rho1, e):
+    return veca_hash(big_bytes(rho0), big_bytes(rho1), *[b"".join(big_bytes(x) for x in row) for row in e])
+
+
+def veca_encrypt(v, r, s_r, g, GenG, GenH, reader, k=VECA_K):
+    """Encrypt, go/ve-ca/main.go:18-92.  Draw order: p[0..3][k], then x[0..1][k] (MustSampleRandomF)."""
+    p = [[rand_int(reader) for _ in range(k)] for _ in range(4)]
+    x = [[rand_int(reader) for _ in range(k)] for _ in range(2)]
+    s = [[pow(s_r, p[i][j], N) for j in range(k)] for i in range(4)]
+    X = [add(mul(x[0][i], GenH), mul(x[1][i], GenG)) for i in range(k)]
+    C = add(mul(v, GenH), mul(r, GenG))
+    rho0, rho1 = _veca_rho(GenG, GenH, C, X)
+    alpha = [[0] * k for _ in range(4)]
+    e = [[0] * k for _ in range(4)]
+    for i in range(k):
+        alpha[0][i] = (x[0][i] - rho0 * v) % N
+        alpha[1][i] = (x[0][i] - rho1 * v) % N
+        alpha[2][i] = (x[1][i] - rho0 * r) % N
+        alpha[3][i] = (x[1][i] - rho1 * r) % N
+        for t in range(4):
+            e[t][i] = veca_e(s[t][i], alpha[t][i])
+    c = _veca_c(rho0, rho1, e)
+    proof = {"E": e, "X": X, "Alpha": [[0] * k, [0] * k], "P": [[0] * k, [0] * k], "Share": [[0] * k, [0] * k]}
+    for i in range(k):
+        b = (c >> i) & 1
+        proof["Alpha"][0][i] = alpha[b][i]
+        proof["Alpha"][1][i] = alpha[b + 2][i]
+        proof["P"][0][i] = p[b][i]
+        proof["P"][1][i] = p[b + 2][i]
+        d = 1 - b
+        proof["Share"][0][i] = pow(g, p[d][i], N)
+        proof["Share"][1][i] = pow(g, p[d + 2][i], N)
+    return proof, C
+
+
+def veca_verify(proof, s_r, C, GenG, GenH, k=VECA_K):
+    """Verify, go/ve-ca/main.go:94-133.  Returns None, or the message the reference prints."""
+    rho = _veca_rho(GenG, GenH, C, proof["X"])
+    c = _veca_c(rho[0], rho[1], proof["E"])
+    for i in range(k):
+        b = (c >> i) & 1
+        X = add(add(mul(proof["Alpha"][0][i], GenH), mul(proof["Alpha"][1][i], GenG)), mul(rho[b], C))
+        if marshal(X) != marshal(proof["X"][i]):
+            return "invalid sigma answer"
+        e0 = veca_e(pow(s_r, proof["P"][0][i], N), proof["Alpha"][0][i])
+        e1 = veca_e(pow(s_r, proof["P"][1][i], N), proof["Alpha"][1][i])
+        if big_bytes(e0) != big_bytes(proof["E"][b][i]):
+            return "invalid e0 answer"
+        if big_bytes(e1) != big_bytes(proof["E"][b + 2][i]):
+            return "invalid e1 answer"
+    return None
+
+
+def veca_decrypt(u, proof, C, GenG, GenH, k=VECA_K):
+    """Decrypt, go/ve-ca/main.go:135-174."""
+    rho = _veca_rho(GenG, GenH, C, proof["X"])
+    c = _veca_c(rho[0], rho[1], proof["E"])
+    for i in range(k):
+        b = (c >> i) & 1
+        d = 1 - b
+        key_v = pow(proof["Share"][0][i], u, N)
+        key_r = pow(proof["Share"][1][i], u, N)
+        alpha0 = veca_e(key_v, proof["E"][d][i])
+        alpha1 = veca_e(key_r, proof["E"][d + 2][i])
+        den = pow((rho[b] - rho[d]) % N, -1, N)
+        v = (alpha0 - proof["Alpha"][0][i]) % N * den % N
+        r = (alpha1 - proof["Alpha"][1][i]) % N * den % N
+        if marshal(add(mul(v, GenH), mul(r, GenG))) == marshal(C):
+            return v, r
+    raise ValueError("Failed to recover")
+
+
+def veca_proof_bytes(proof, k=VECA_K) -> bytes:
+    """Wire format used by libbpamd (the reference defines none): E[4][k] | Alpha[2][k] | P[2][k] |
+    Share[2][k] as 32-byte big-endian each, then X[k] as Marshal() bytes."""
+    out = b""
+    for name, rows in (("E", 4), ("Alpha", 2), ("P", 2), ("Share", 2)):
+        for t in range(rows):
+            out += b"".join(x.to_bytes(32, "big") for x in proof[name][t])
+    return out + b"".join(marshal(x) for x in proof["X"])

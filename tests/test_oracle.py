@@ -289,3 +289,35 @@ def test_vector_mul_on_matrix_reference_answer():
     import bn256_ref as ref
     assert ref.vector_mul_on_matrix([10, 5], [[1, 2], [3, 4]]) == [25, 40]
     assert ref.matrix_mul_on_vector([10, 5], [[1, 2], [3, 4]]) == [20, 50]  # rows: go/bppp/util.go:311-319
+
+
+def test_f4_restatements_match_committed_vectors():
+    """go/schnorr-bn256 and go/ve-ca restatements (oracle/bn256_ref.py) against tests/golden/f4.json, and the
+    self-consistency the reference's own tests check: aggregated signature verifies
+    (schnorr_test.go:16-80), Encrypt -> Verify -> Decrypt returns (v, r) (ve-ca/main_test.go:10-37)."""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f4.json")) as f:
+        d = json.load(f)
+    sc = d["schnorr"]
+    G, Pub, Rc = (ref.unmarshal(bytes.fromhex(sc[k])) for k in ("G", "pub_common", "R_common"))
+    m = ref.schnorr_msg(b"Hello world")
+    assert hex(m) == sc["msg_hello_world"]
+    assert ref.schnorr_verify((Rc, int(sc["combined_S"], 16)), Pub, G, m)
+    assert not ref.schnorr_verify((Rc, int(sc["alice_S"], 16)), Pub, G, m)
+    a = sc["alice"]
+    assert ref.marshal(ref.mul(int(a["prv"], 16), G)).hex() == a["pub"]
+    sg = ref.schnorr_sign(int(a["prv"], 16), ref.unmarshal(bytes.fromhex(a["pub"])), G, m, ref.ByteStream(d["seeds"]["sign"]))
+    assert (ref.marshal(sg[0]).hex(), hex(sg[1])) == (sc["single"]["R"], sc["single"]["S"])
+    assert ref.big_bytes(0) == b"" and ref.big_bytes(256) == b"\x01\x00"
+    vc = d["veca"]
+    GenG, GenH = ref.unmarshal(bytes.fromhex(vc["GenG"])), ref.unmarshal(bytes.fromhex(vc["GenH"]))
+    v, r, g, share, u = (int(vc[k], 16) for k in ("v", "r", "g", "receiver_share", "receiver_prv"))
+    assert pow(g, u, ref.N) == share
+    proof, C = ref.veca_encrypt(v, r, share, g, GenG, GenH, ref.ByteStream(d["seeds"]["encrypt"]))
+    assert ref.marshal(C).hex() == vc["C"]
+    assert hashlib.sha256(ref.veca_proof_bytes(proof)).hexdigest() == vc["proof_sha256"]
+    assert ref.veca_verify(proof, share, C, GenG, GenH) is None
+    assert ref.veca_decrypt(u, proof, C, GenG, GenH) == (v, r)
+    assert ref.veca_e(ref.veca_e(5, 99), 5) == 99        # D(key, E(key, value)) = value, enc_test.go:9-27
