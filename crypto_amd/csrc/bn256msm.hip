@@ -555,28 +555,59 @@ struct msm_pending {
 };
 static void pending_free(msm_pending* p) { delete p; }
 
-// Enqueues the device pipeline for one range of a bases handle (view: off, stride) with
-// device-resident scalars (view: sc_stride) on ctx->stream, up to the copy of the packed bucket
-// sums into ctx->h_pack.  With hold_stream the host never waits for the stream here (a call of
-// several passes then reports the phase times of its last pass only).
-static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
-                       const uint8_t* d_scalars, size_t sc_stride, bool hold_stream, msm_pending* pend) {
+// One term of a sum of MSMs: a range of a bases handle (view: off, stride) and its device-resident
+// scalars (view: sc_stride).
+struct msm_src {
+  const bn256_bases* b;
+  size_t off, stride, n;
+  const uint8_t* sc;
+  size_t sc_stride;
+};
+
+// Enqueues the device pipeline for the sum of `nsrc` such terms on ctx->stream, up to the copy of the
+// packed bucket sums into ctx->h_pack.  Several terms need fixed-base tables of one window width: they
+// share the single bucket set, every term contributes its passes (sub-ranges of <= MSM_CHUNK points),
+// k_add_buckets adds the passes' bucket sums and the reduction and host tail run ONCE -- the BP++
+// commitments <HVec, r||l> + <GVec, n> (go/bppp/docs_test.go:560-564) are one pipeline this way.
+// A table-less call has one term (callers gather several into one first).  With hold_stream the host
+// never waits for the stream here (a call of several passes then reports the phase times of its last
+// pass only).
+static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool hold_stream, msm_pending* pend) {
   using namespace hostg1;
   pend->empty = true;
   for (float& f : ctx->last_ms) f = 0.f;
-  if (n == 0) return BN256_OK;
-  const bool precomp = b->levels > 1;
-  const int c = precomp ? b->c : pick_c(ctx, n, false);
+  const bn256_bases* b0 = nullptr;
+  size_t n_total = 0, n_single = 0;
+  int live = 0;
+  for (int i = 0; i < nsrc; i++) {
+    if (!srcs[i].n) continue;
+    if (!b0) b0 = srcs[i].b;
+    n_total += srcs[i].n;
+    n_single = srcs[i].n;
+    live++;
+  }
+  if (!live) return BN256_OK;
+  const bool precomp = b0->levels > 1;
+  if (!precomp && live > 1) return BN256_EINVAL;
+  const int c = precomp ? b0->c : pick_c(ctx, n_single, false);
   const int W = windows_for(c);
-  if (precomp && W != b->levels) return BN256_EINVAL;
   const u32 nb = 1u << (c - 1);
   const u32 nsets = precomp ? 1u : (u32)W;
   const size_t nbt = (size_t)nb * nsets;
-  if ((unsigned long long)b->n * b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
   const u32 q = (u32)(c - 1);
   const size_t chunk = ctx->msm_chunk ? ctx->msm_chunk : MSM_CHUNK;
-  const size_t nchunks = (precomp && n > chunk) ? (n + chunk - 1) / chunk : 1;
-  const size_t nmax = nchunks > 1 ? chunk : n;  // largest pass
+  // the passes: every term in sub-ranges of <= chunk points (table-less: the one term, one pass)
+  size_t npasses = 0, nmax = 0;
+  for (int i = 0; i < nsrc; i++) {
+    const msm_src& t = srcs[i];
+    if (!t.n) continue;
+    if ((t.b->levels > 1) != precomp || (precomp && (t.b->c != c || t.b->levels != W))) return BN256_EINVAL;
+    if ((unsigned long long)t.b->n * t.b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
+    const size_t np = (precomp && t.n > chunk) ? (t.n + chunk - 1) / chunk : 1;
+    npasses += np;
+    nmax = std::max(nmax, np > 1 ? chunk : t.n);
+  }
+  const size_t nchunks = npasses;
   const unsigned long long entries_max = (unsigned long long)nmax * W;
   if (entries_max >= (1ull << 31)) return BN256_ETOOLARGE;
   const u32 nscan = nblocks(nbt + 1, SCAN_TILE);
@@ -639,7 +670,11 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
     u32 K = pick_k(m);
     return (size_t)((e + K - 1) / K);
   };
-  const size_t Tmax = std::max(threads_for(nmax), threads_for(n - (nchunks - 1) * nmax));
+  size_t Tmax = threads_for(nmax);
+  for (int i = 0; i < nsrc; i++) {  // a short last pass has a shorter chunk length and may have more threads
+    const size_t np = (precomp && srcs[i].n > chunk) ? (srcs[i].n + chunk - 1) / chunk : 1;
+    if (srcs[i].n) Tmax = std::max(Tmax, threads_for(srcs[i].n - (np - 1) * (np > 1 ? chunk : 0)));
+  }
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
   if ((rc = ws_reserve(ctx, WS_HEAVYTMP, (size_t)HEAVY_SLOTS * HEAVY_PARTS * sizeof(xyzz_mem)))) return rc;
@@ -668,10 +703,17 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
 
-  for (size_t ch = 0; ch < nchunks; ch++) {
-    const size_t n_ch = std::min(nmax, n - ch * nmax);
-    const size_t off_ch = off + ch * nmax * stride;
-    const uint8_t* sc_ch = d_scalars + ch * nmax * sc_stride * 32;
+  size_t ch = 0;  // running pass number over all terms
+  for (int si = 0; si < nsrc; si++) {
+   const msm_src& t = srcs[si];
+   if (!t.n) continue;
+   const bn256_bases* b = t.b;
+   const size_t stride = t.stride, sc_stride = t.sc_stride;
+   const size_t np_t = (precomp && t.n > chunk) ? (t.n + chunk - 1) / chunk : 1, len_t = np_t > 1 ? chunk : t.n;
+   for (size_t cj = 0; cj < np_t; cj++, ch++) {
+    const size_t n_ch = std::min(len_t, t.n - cj * len_t);
+    const size_t off_ch = t.off + cj * len_t * stride;
+    const uint8_t* sc_ch = t.sc + cj * len_t * sc_stride * 32;
     const unsigned long long entries = (unsigned long long)n_ch * W;
     const u32 K = pick_k(n_ch);
     const size_t T = threads_for(n_ch);
@@ -769,6 +811,7 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
         ctx->last_ms[6] += ms;
       }
     }
+   }
   }
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
@@ -813,6 +856,12 @@ static int msm_finish(bn256_ctx* ctx, const msm_pending* pend, hostg1::Pt* resul
   }
   *result = total;
   return BN256_OK;
+}
+
+static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
+                       const uint8_t* d_scalars, size_t sc_stride, bool hold_stream, msm_pending* pend) {
+  const msm_src one = {b, off, stride, n, d_scalars, sc_stride};
+  return msm_enqueue_srcs(ctx, &one, 1, hold_stream, pend);
 }
 
 static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
@@ -986,6 +1035,31 @@ static int multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, con
     if (hold_stream) HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's buffer is not ours after return
     return msm_enqueue(ctx, b[0], off[0], stride ? stride[0] : 1, n[0], (const uint8_t*)ctx->ws[WS_SCALARS], 1, hold_stream,
                        pend);
+  }
+  // every segment over a fixed-base table of one window width: the segments are the terms of one
+  // pipeline (shared bucket set, one reduction, one host tail), nothing is gathered
+  bool all_tables = true;
+  int c0 = 0, live = 0;
+  for (int i = 0; i < k; i++) {
+    if (!n[i]) continue;
+    live++;
+    if (b[i]->levels <= 1 || (c0 && b[i]->c != c0)) all_tables = false;
+    c0 = b[i]->c;
+  }
+  if (all_tables && live <= 16 && total_n < (1ull << 31)) {
+    if ((rc = ws_reserve(ctx, WS_SCALARS, total_n * 32))) return rc;
+    uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
+    msm_src srcs[16];
+    int m = 0;
+    size_t pos = 0;
+    for (int i = 0; i < k; i++) {
+      if (!n[i]) continue;
+      HIPCHK(hipMemcpyAsync(sc + pos * 32, scalars_be[i], n[i] * 32, hipMemcpyHostToDevice, ctx->stream));
+      srcs[m++] = msm_src{b[i], off[i], stride ? stride[i] : 1, n[i], sc + pos * 32, 1};
+      pos += n[i];
+    }
+    if (hold_stream) HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's buffers are not ours after return
+    return msm_enqueue_srcs(ctx, srcs, m, hold_stream, pend);
   }
   if (big_table || total_n >= (1ull << 31)) {
     *single = false;
@@ -1791,6 +1865,26 @@ static int fr_multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, 
   if (total == 0) return BN256_OK;
   if (total >= (1ull << 31)) return BN256_ETOOLARGE;
   HIPCHK(hipSetDevice(ctx->device));
+  {
+    // every segment over a fixed-base table of one window width, unscaled: the views are the terms of
+    // one pipeline as they stand (the BP++ commitments <HVec, r||l> + <GVec, n> over resident
+    // generators and scalars, go/bppp/docs_test.go:560-564,588-589,1002-1003) -- nothing is gathered
+    bool all_tables = true;
+    int c0 = 0, live = 0;
+    for (int i = 0; i < k; i++) {
+      if (!n[i]) continue;
+      live++;
+      if (b[i]->levels <= 1 || (c0 && b[i]->c != c0) || (scale_be && scale_be[i])) all_tables = false;
+      c0 = b[i]->c;
+    }
+    if (all_tables && live <= 16) {
+      msm_src srcs[16];
+      int m = 0;
+      for (int i = 0; i < k; i++)
+        if (n[i]) srcs[m++] = msm_src{b[i], off[i], stride[i], n[i], v[i]->d + v_off[i] * 32, v_stride[i]};
+      return msm_enqueue_srcs(ctx, srcs, m, hold_stream, pend);
+    }
+  }
   if ((rc = ws_reserve(ctx, WS_GATHER, total * sizeof(aff_mem))) || (rc = ws_reserve(ctx, WS_SCALARS, total * 32))) return rc;
   aff_mem* pts = (aff_mem*)ctx->ws[WS_GATHER];
   uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
