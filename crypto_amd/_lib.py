@@ -14,7 +14,7 @@ EXPORTS = [
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
-    "bn256_fr_fold", "bn256_fr_dot", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait", "bn256_ctx_drain",
+    "bn256_fr_fold", "bn256_fr_dot", "bn256_fr_fold_multi", "bn256_fr_dot_multi", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait", "bn256_ctx_drain",
 ]
 
 _lib = None
@@ -75,6 +75,9 @@ def load() -> C.CDLL:
     lib.bn256_fr_free.restype = None
     lib.bn256_fr_fold.argtypes = [vp, vp, sz, sz, vp, sz, sz, sz, u8p, u8p, C.POINTER(vp)]
     lib.bn256_fr_dot.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, sz, u8p, u8p]
+    psz, pvp = C.POINTER(sz), C.POINTER(vp)
+    lib.bn256_fr_fold_multi.argtypes = [vp, i, pvp, psz, psz, pvp, psz, psz, psz, u8p, u8p, pvp]
+    lib.bn256_fr_dot_multi.argtypes = [vp, i, pvp, psz, psz, psz, pvp, psz, psz, psz, C.POINTER(u8p), u8p]
     lib.bn256_msm_fr.argtypes = [vp, vp, sz, sz, sz, vp, sz, sz, u8p]
     lib.bn256_msm_fr_multi.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(vp),
                                        C.POINTER(sz), C.POINTER(sz), C.POINTER(u8p), u8p]

@@ -2,10 +2,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -188,7 +191,8 @@ struct bn256_ctx {
   // bn256_msm_submit / bn256_msm_wait: each lane is a whole child context (own stream, workspaces,
   // pinned result buffer) on the same device, created on first use
   bn256_ctx* lane[BN256_ASYNC_LANES];
-  struct msm_pending* pending[BN256_ASYNC_LANES];
+  struct lane_worker* worker[BN256_ASYNC_LANES];  // the lane's host thread: enqueue, wait and host tail of a submitted call
+  struct lane_ticket* pending[BN256_ASYNC_LANES];
   // bn256_ctx_create_multi: this context is only the parent of nshard ordinary contexts, one per
   // entry of the device list (it has no stream or workspace of its own)
   int nshard;
@@ -260,7 +264,7 @@ extern "C" const char* bn256_strerror(int code) {
 
 // Everything bn256_ctx_create made, in reverse; `counted` = pool::context_created() has run.  Also the
 // failure path of bn256_ctx_create, so that a half-built context is not leaked.
-static void pending_free(struct msm_pending* p);
+static void lane_shutdown(bn256_ctx* ctx, int l);
 static void ctx_teardown(bn256_ctx* ctx, bool counted) {
   if (ctx->nshard) {  // a multi-device parent owns nothing but its shards
     for (int s = 0; s < ctx->nshard; s++) bn256_ctx_destroy(ctx->shard[s]);
@@ -270,7 +274,7 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < BN256_ASYNC_LANES; i++) {
-    pending_free(ctx->pending[i]);
+    lane_shutdown(ctx, i);  // waits for a submitted call, ends the lane's thread
     bn256_ctx_destroy(ctx->lane[i]);
   }
   for (int i = 0; i < WS_COUNT; i++)
@@ -501,10 +505,12 @@ extern "C" int bn256_bases_upload(bn256_ctx* ctx, const uint8_t* xy_be, size_t n
   return BN256_OK;
 }
 
-// A submitted MSM call (bn256_msm_submit) may still read the handle: wait for the lanes that hold one.
+// A submitted call (bn256_msm_submit, bn256_fold2_submit) may still read the handle: wait for the lanes
+// that hold one (the call itself, not only its stream: the lane's thread may not have enqueued it yet).
+static void lane_join(bn256_ctx* ctx, int l);
 static void wait_for_submitted(bn256_ctx* ctx) {
   for (int i = 0; i < BN256_ASYNC_LANES; i++)
-    if (ctx->lane[i] && ctx->pending[i]) (void)hipStreamSynchronize(ctx->lane[i]->stream);
+    if (ctx->lane[i] && ctx->pending[i]) lane_join(ctx, i);
 }
 
 extern "C" void bn256_bases_free(bn256_ctx* ctx, bn256_bases* b) {
@@ -549,11 +555,104 @@ struct msm_pending {
   bool empty;   // n == 0: nothing was enqueued, the result is the identity
   int c;
   u32 q, nsets;
-  bool ready = false;  // bn256_msm_multi_submit on a shape that has no single pipeline: computed at submit
-  uint8_t ready_xy[64];
-  bool fold = false;   // a bn256_fold2_submit ticket: nothing to finish but the lane's stream
 };
-static void pending_free(msm_pending* p) { delete p; }
+
+// ---------------------------------------------------------------------------- lanes
+// bn256_msm_submit and its relatives hand the whole call -- enqueueing ~30 launches (~0.1 ms of host
+// time), waiting for the stream, the host tail (~0.03-0.1 ms) -- to the lane's own host thread, so the
+// caller's thread is free at once: a prover's round has two or three such calls plus host work of its
+// own (go/bp/main.go:340-347, go/bppp/docs_test.go:1312-1320), and done one after the other on one
+// thread they were ~0.6 ms per WNLA round of pure host latency.  A lane runs one call at a time.
+struct lane_ticket {
+  bool fold = false;  // a bn256_fold2_submit ticket (finished by bn256_fold_wait)
+  int rc = BN256_OK;
+  uint8_t xy[64] = {0};
+  float ms[7] = {0};
+  char msg[sizeof g_hip_msg] = {0};
+};
+struct lane_worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool busy = false, quit = false;
+};
+static void lane_worker_main(lane_worker* w, int device) {
+  (void)hipSetDevice(device);
+  std::unique_lock<std::mutex> lk(w->mu);
+  for (;;) {
+    w->cv.wait(lk, [&] { return w->quit || w->job; });
+    if (w->quit && !w->job) return;
+    std::function<void()> job = std::move(w->job);
+    w->job = nullptr;
+    lk.unlock();
+    job();
+    lk.lock();
+    w->busy = false;
+    w->cv.notify_all();
+  }
+}
+// a free lane (context and thread are created on first use)
+static int lane_acquire(bn256_ctx* ctx, int* out) {
+  int l = 0, rc;
+  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
+  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
+  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
+  if (!ctx->worker[l]) {
+    lane_worker* w = new (std::nothrow) lane_worker();
+    if (!w) return BN256_ENOMEM;
+    w->th = std::thread(lane_worker_main, w, ctx->device);
+    ctx->worker[l] = w;
+  }
+  ctx->lane[l]->tune_c = ctx->tune_c;
+  ctx->lane[l]->tune_k = ctx->tune_k;
+  *out = l;
+  return BN256_OK;
+}
+// runs fn(lane context, ticket) -> rc on the lane's thread; the ticket keeps rc, message and timings
+static int lane_start(bn256_ctx* ctx, int l, bool fold, std::function<int(bn256_ctx*, lane_ticket*)> fn) {
+  lane_ticket* t = new (std::nothrow) lane_ticket();
+  if (!t) return BN256_ENOMEM;
+  t->fold = fold;
+  bn256_ctx* lane = ctx->lane[l];
+  lane_worker* w = ctx->worker[l];
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->busy = true;
+    w->job = [lane, t, fn] {
+      g_hip_msg[0] = 0;
+      t->rc = fn(lane, t);
+      if (t->rc) (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
+      memcpy(t->msg, g_hip_msg, sizeof t->msg);
+      memcpy(t->ms, lane->last_ms, sizeof t->ms);
+    };
+  }
+  w->cv.notify_all();
+  ctx->pending[l] = t;
+  return BN256_OK;
+}
+static void lane_join(bn256_ctx* ctx, int l) {
+  lane_worker* w = ctx->worker[l];
+  if (!w) return;
+  std::unique_lock<std::mutex> lk(w->mu);
+  w->cv.wait(lk, [&] { return !w->busy; });
+}
+static void lane_shutdown(bn256_ctx* ctx, int l) {
+  lane_worker* w = ctx->worker[l];
+  if (w) {
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return !w->busy; });
+      w->quit = true;
+    }
+    w->cv.notify_all();
+    w->th.join();
+    delete w;
+    ctx->worker[l] = nullptr;
+  }
+  delete ctx->pending[l];
+  ctx->pending[l] = nullptr;
+}
 
 // One term of a sum of MSMs: a range of a bases handle (view: off, stride) and its device-resident
 // scalars (view: sc_stride).
@@ -945,22 +1044,16 @@ extern "C" int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off
   int rc = range_check(b, off, n);
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
-  int l = 0;
-  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
-  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
-  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
-  bn256_ctx* lane = ctx->lane[l];
-  lane->tune_c = ctx->tune_c;
-  lane->tune_k = ctx->tune_k;
-  msm_pending* pend = new (std::nothrow) msm_pending();
-  if (!pend) return BN256_ENOMEM;
-  rc = msm_enqueue(lane, b, off, 1, n, (const uint8_t*)d_scalars_be, 1, true, pend);
-  if (rc) {
-    (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
-    delete pend;
-    return rc;
-  }
-  ctx->pending[l] = pend;
+  int l;
+  if ((rc = lane_acquire(ctx, &l))) return rc;
+  const uint8_t* sc = (const uint8_t*)d_scalars_be;
+  rc = lane_start(ctx, l, false, [b, off, n, sc](bn256_ctx* lane, lane_ticket* t) -> int {
+    hostg1::Pt r;
+    int rc2 = msm_core(lane, b, off, 1, n, sc, &r);
+    if (!rc2) hostg1::marshal(t->xy, r);
+    return rc2;
+  });
+  if (rc) return rc;
   *ticket = l;
   return BN256_OK;
 }
@@ -969,22 +1062,17 @@ extern "C" int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64])
   if (!ctx || !out_xy_be || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket] || ctx->pending[ticket]->fold)
     return BN256_EINVAL;
   SINGLE_DEVICE_ONLY(ctx);
-  HIPCHK(hipSetDevice(ctx->device));
-  bn256_ctx* lane = ctx->lane[ticket];
-  msm_pending* pend = ctx->pending[ticket];
+  lane_join(ctx, ticket);
+  lane_ticket* t = ctx->pending[ticket];
   ctx->pending[ticket] = nullptr;
-  if (pend->ready) {
-    memcpy(out_xy_be, pend->ready_xy, 64);
-    delete pend;
-    return BN256_OK;
-  }
-  hostg1::Pt r;
-  int rc = msm_finish(lane, pend, &r);
-  delete pend;
-  for (int i = 0; i < 7; i++) ctx->last_ms[i] = lane->last_ms[i];
-  if (rc) return rc;
-  hostg1::marshal(out_xy_be, r);
-  return BN256_OK;
+  const int rc = t->rc;
+  for (int i = 0; i < 7; i++) ctx->last_ms[i] = t->ms[i];
+  if (rc)
+    memcpy(g_hip_msg, t->msg, sizeof g_hip_msg);
+  else
+    memcpy(out_xy_be, t->xy, 64);
+  delete t;
+  return rc;
 }
 
 static int msm_host_scalars(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
@@ -1137,27 +1225,31 @@ extern "C" int bn256_msm_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* 
   SINGLE_DEVICE_ONLY(ctx);
   *ticket = -1;
   HIPCHK(hipSetDevice(ctx->device));
-  int l = 0, rc;
-  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
-  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
-  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
-  bn256_ctx* lane = ctx->lane[l];
-  lane->tune_c = ctx->tune_c;
-  lane->tune_k = ctx->tune_k;
-  msm_pending* pend = new (std::nothrow) msm_pending();
-  if (!pend) return BN256_ENOMEM;
-  bool single = true;
-  rc = multi_enqueue(lane, k, b, off, nullptr, n, scalars_be, true, pend, &single);
-  if (!rc && !single) {  // several large fixed-base tables: no single pipeline to enqueue, done here
-    rc = bn256_msm_multi_strided(lane, k, b, off, nullptr, n, scalars_be, pend->ready_xy);
-    pend->ready = true;
+  int l, rc;
+  for (int i = 0; i < k; i++) {
+    if (!b[i] || (!scalars_be[i] && n[i])) return BN256_EINVAL;
+    if ((rc = range_check(b[i], off[i], n[i]))) return rc;
   }
-  if (rc) {
-    (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
-    delete pend;
-    return rc;
+  if ((rc = lane_acquire(ctx, &l))) return rc;
+  // the caller's arrays and scalars are not ours after return: the call owns copies
+  struct args_t {
+    std::vector<const bn256_bases*> b;
+    std::vector<size_t> off, n;
+    std::vector<std::vector<uint8_t>> sc;
+    std::vector<const uint8_t*> ptr;
+  };
+  auto a = std::make_shared<args_t>();
+  for (int i = 0; i < k; i++) {
+    a->b.push_back(b[i]);
+    a->off.push_back(off[i]);
+    a->n.push_back(n[i]);
+    a->sc.emplace_back(scalars_be[i], scalars_be[i] + n[i] * 32);
   }
-  ctx->pending[l] = pend;
+  for (auto& v : a->sc) a->ptr.push_back(v.data());
+  rc = lane_start(ctx, l, false, [a, k](bn256_ctx* lane, lane_ticket* t) -> int {
+    return bn256_msm_multi_strided(lane, k, a->b.data(), a->off.data(), nullptr, a->n.data(), a->ptr.data(), t->xy);
+  });
+  if (rc) return rc;
   *ticket = l;
   return BN256_OK;
 }
@@ -1480,7 +1572,22 @@ extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const 
   return BN256_OK;
 }
 
-// fold + normalisation on `on`'s stream and scratch; the caller synchronises
+// fold + normalisation into the handle r (max(n_lo, n_hi) points) on `on`'s stream and scratch; the
+// caller synchronises
+static int fold2_into(bn256_ctx* on, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                      size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                      bn256_bases* r) {
+  size_t n = std::max(n_lo, n_hi);
+  HIPCHK(hipSetDevice(on->device));
+  if (n) {
+    xyzz_mem* xs;
+    int rc = fold_points(on, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, s_lo_be,
+                         s_hi_be, (u32)n_lo, (u32)n_hi, &xs);
+    if (rc) return rc;
+    normalize_into(on, xs, r->d, n);
+  }
+  return BN256_OK;
+}
 static int fold2_enqueue(bn256_ctx* on, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
                          size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
                          bn256_bases** out) {
@@ -1488,18 +1595,12 @@ static int fold2_enqueue(bn256_ctx* on, const bn256_bases* lo, size_t lo_off, si
   int rc;
   if ((rc = range_check(lo, lo_off, n_lo, stride))) return rc;
   if ((rc = range_check(hi, hi_off, n_hi, stride))) return rc;
-  size_t n = std::max(n_lo, n_hi);
   HIPCHK(hipSetDevice(on->device));
-  bn256_bases* r = bases_alloc(n, 1, 0, &rc);
+  bn256_bases* r = bases_alloc(std::max(n_lo, n_hi), 1, 0, &rc);
   if (!r) return rc;
-  if (n) {
-    xyzz_mem* xs;
-    if ((rc = fold_points(on, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, s_lo_be,
-                          s_hi_be, (u32)n_lo, (u32)n_hi, &xs))) {
-      bn256_bases_free(on, r);
-      return rc;
-    }
-    normalize_into(on, xs, r->d, n);
+  if ((rc = fold2_into(on, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, r))) {
+    bn256_bases_free(on, r);
+    return rc;
   }
   *out = r;
   return BN256_OK;
@@ -1530,20 +1631,32 @@ extern "C" int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t 
   *out = nullptr;
   *ticket = -1;
   HIPCHK(hipSetDevice(ctx->device));
-  int l = 0, rc;
-  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
-  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
-  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
-  msm_pending* pend = new (std::nothrow) msm_pending();
-  if (!pend) return BN256_ENOMEM;
-  pend->empty = true;
-  pend->fold = true;
-  if ((rc = fold2_enqueue(ctx->lane[l], lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, out))) {
-    (void)hipStreamSynchronize(ctx->lane[l]->stream);
-    delete pend;
+  int l, rc;
+  if ((rc = range_check(lo, lo_off, n_lo, stride)) || (rc = range_check(hi, hi_off, n_hi, stride))) return rc;
+  if ((rc = lane_acquire(ctx, &l))) return rc;
+  // the new handle exists at once (its memory comes from the caller's thread); the lane fills it
+  bn256_bases* r = bases_alloc(std::max(n_lo, n_hi), 1, 0, &rc);
+  if (!r) return rc;
+  struct sc_t {
+    uint8_t lo[32], hi[32];
+  } sc;
+  memcpy(sc.lo, s_lo_be, 32);
+  memcpy(sc.hi, s_hi_be, 32);
+  rc = lane_start(ctx, l, true, [=](bn256_ctx* lane, lane_ticket*) -> int {
+    int rc2 = fold2_into(lane, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, sc.lo, sc.hi, r);
+    if (rc2) return rc2;
+    hipError_t e = hipStreamSynchronize(lane->stream);
+    if (e != hipSuccess) {
+      ctx_note_hip(e, __LINE__);
+      return BN256_EHIP;
+    }
+    return BN256_OK;
+  });
+  if (rc) {
+    bn256_bases_free(nullptr, r);
     return rc;
   }
-  ctx->pending[l] = pend;
+  *out = r;
   *ticket = l;
   return BN256_OK;
 }
@@ -1562,10 +1675,11 @@ extern "C" int bn256_ctx_drain(bn256_ctx* ctx) {
   hipError_t first = hipStreamSynchronize(ctx->stream);
   for (int l = 0; l < BN256_ASYNC_LANES; l++) {
     if (ctx->lane[l]) {
+      lane_join(ctx, l);
       hipError_t e = hipStreamSynchronize(ctx->lane[l]->stream);
       if (e != hipSuccess && first == hipSuccess) first = e;
     }
-    pending_free(ctx->pending[l]);  // the ticket is void from here on
+    delete ctx->pending[l];  // the ticket is void from here on
     ctx->pending[l] = nullptr;
   }
   HIPCHK(first);
@@ -1576,15 +1690,13 @@ extern "C" int bn256_fold_wait(bn256_ctx* ctx, int ticket) {
   if (!ctx || ticket < 0 || ticket >= BN256_ASYNC_LANES || !ctx->pending[ticket] || !ctx->pending[ticket]->fold)
     return BN256_EINVAL;
   SINGLE_DEVICE_ONLY(ctx);
-  HIPCHK(hipSetDevice(ctx->device));
-  delete ctx->pending[ticket];
+  lane_join(ctx, ticket);
+  lane_ticket* t = ctx->pending[ticket];
   ctx->pending[ticket] = nullptr;
-  hipError_t e = hipStreamSynchronize(ctx->lane[ticket]->stream);
-  if (e != hipSuccess) {
-    ctx_note_hip(e, __LINE__);
-    return BN256_EHIP;
-  }
-  return BN256_OK;
+  const int rc = t->rc;
+  if (rc) memcpy(g_hip_msg, t->msg, sizeof g_hip_msg);
+  delete t;
+  return rc;
 }
 
 extern "C" int bn256_fold(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, const bn256_bases* hi, size_t hi_off,
@@ -1779,27 +1891,101 @@ static fr_arg fr_arg_canon(fr_arg a) {
   return a;
 }
 
+extern "C" int bn256_fr_fold_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
+                                   const size_t* n_a, const bn256_frvec* const* b, const size_t* b_off, const size_t* n_b,
+                                   const size_t* stride, const uint8_t* s_a_be, const uint8_t* s_b_be, bn256_frvec** out) {
+  if (!ctx || k < 0 || (k && (!a || !a_off || !n_a || !b || !b_off || !n_b || !stride || !s_a_be || !s_b_be || !out)))
+    return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
+  int rc;
+  for (int i = 0; i < k; i++) {
+    out[i] = nullptr;
+    if (!a[i] || !b[i]) return BN256_EINVAL;
+    if ((rc = fr_range_check(a[i], a_off[i], n_a[i], stride[i])) || (rc = fr_range_check(b[i], b_off[i], n_b[i], stride[i])))
+      return rc;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  auto undo = [&]() {
+    for (int i = 0; i < k; i++) {
+      if (out[i]) bn256_fr_free(ctx, out[i]);
+      out[i] = nullptr;
+    }
+  };
+  for (int i = 0; i < k; i++) {
+    const size_t n = std::max(n_a[i], n_b[i]);
+    if (!(out[i] = frvec_alloc(n, &rc))) {
+      undo();
+      return rc;
+    }
+    if (n)
+      hipLaunchKernelGGL(k_fr_fold, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
+                         (const uint8_t*)(a[i]->d + a_off[i] * 32), (u32)n_a[i], (const uint8_t*)(b[i]->d + b_off[i] * 32),
+                         (u32)n_b[i], (u32)stride[i], fr_arg_canon(fr_arg_from_be(s_a_be + 32 * i)),
+                         fr_arg_canon(fr_arg_from_be(s_b_be + 32 * i)), out[i]->d, (u32)n);
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);  // one wait for all k folds
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    undo();
+    return BN256_EHIP;
+  }
+  return BN256_OK;
+}
+
 extern "C" int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t n_a, const bn256_frvec* b,
                              size_t b_off, size_t n_b, size_t stride, const uint8_t s_a_be[32],
                              const uint8_t s_b_be[32], bn256_frvec** out) {
   if (!ctx || !a || !b || !out || !s_a_be || !s_b_be) return BN256_EINVAL;
+  return bn256_fr_fold_multi(ctx, 1, &a, &a_off, &n_a, &b, &b_off, &n_b, &stride, s_a_be, s_b_be, out);
+}
+
+extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
+                                  const size_t* a_stride, const size_t* n_a, const bn256_frvec* const* b,
+                                  const size_t* b_off, const size_t* b_stride, const size_t* n_b,
+                                  const uint8_t* const* mu_be, uint8_t* out_be) {
+  if (!ctx || k < 0 || (k && (!a || !a_off || !a_stride || !n_a || !b || !b_off || !b_stride || !n_b || !out_be)))
+    return BN256_EINVAL;
   PRIMARY_SHARD(ctx);
-  *out = nullptr;
+  if (!k) return BN256_OK;
   int rc;
-  if ((rc = fr_range_check(a, a_off, n_a, stride)) || (rc = fr_range_check(b, b_off, n_b, stride))) return rc;
-  size_t n = std::max(n_a, n_b);
-  HIPCHK(hipSetDevice(ctx->device));
-  bn256_frvec* r = frvec_alloc(n, &rc);
-  if (!r) return rc;
-  if (n) {
-    hipLaunchKernelGGL(k_fr_fold, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
-                       (const uint8_t*)(a->d + a_off * 32), (u32)n_a, (const uint8_t*)(b->d + b_off * 32), (u32)n_b,
-                       (u32)stride, fr_arg_canon(fr_arg_from_be(s_a_be)), fr_arg_canon(fr_arg_from_be(s_b_be)), r->d,
-                       (u32)n);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_fr_free(ctx, r); return BN256_EHIP; }
+  size_t need = (size_t)k * 32 + 256;
+  bool any = false;
+  for (int i = 0; i < k; i++) {
+    if (!a[i] || !b[i]) return BN256_EINVAL;
+    if ((rc = fr_range_check(a[i], a_off[i], n_a[i], a_stride[i])) || (rc = fr_range_check(b[i], b_off[i], n_b[i], b_stride[i])))
+      return rc;
+    const size_t n = std::min(n_a[i], n_b[i]);  // the padded tail multiplies by zero
+    if (!n) continue;
+    any = true;
+    const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+    need += (size_t)nblocks((n + per - 1) / per, 256) * sizeof(fr) + 256;
   }
-  *out = r;
+  memset(out_be, 0, (size_t)k * 32);
+  if (!any) return BN256_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ws_reserve(ctx, WS_TMP, need))) return rc;
+  uint8_t* d_out = (uint8_t*)ctx->ws[WS_TMP];              // k results, then every product's partial sums
+  uint8_t* cur = d_out + (((size_t)k * 32 + 255) & ~(size_t)255);
+  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)k * 32, ctx->stream));
+  for (int i = 0; i < k; i++) {
+    const size_t n = std::min(n_a[i], n_b[i]);
+    if (!n) continue;
+    const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+    const u32 nthreads = (u32)((n + per - 1) / per);
+    const u32 nblk = nblocks(nthreads, 256);
+    fr* partials = (fr*)cur;
+    cur += ((size_t)nblk * sizeof(fr) + 255) & ~(size_t)255;
+    const uint8_t* mb = mu_be ? mu_be[i] : nullptr;
+    fr_arg mu;
+    memset(&mu, 0, sizeof mu);
+    if (mb) mu = fr_arg_canon(fr_arg_from_be(mb));
+    hipLaunchKernelGGL(k_fr_dot, dim3(nblk), dim3(256), 0, ctx->stream, (const uint8_t*)(a[i]->d + a_off[i] * 32),
+                       (u32)a_stride[i], (u32)n_a[i], (const uint8_t*)(b[i]->d + b_off[i] * 32), (u32)b_stride[i],
+                       (u32)n_b[i], (u32)n, per, mu, (u32)(mb != nullptr), partials);
+    hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, ctx->stream, (const fr*)partials, nblk, d_out + 32 * i);
+  }
+  HIPCHK(hipMemcpyAsync(out_be, d_out, (size_t)k * 32, hipMemcpyDeviceToHost, ctx->stream));  // one copy,
+  HIPCHK(hipStreamSynchronize(ctx->stream));                                                   // one wait
   return BN256_OK;
 }
 
@@ -1807,29 +1993,7 @@ extern "C" int bn256_fr_dot(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, 
                             const bn256_frvec* b, size_t b_off, size_t b_stride, size_t n_b, const uint8_t* mu_be,
                             uint8_t out_be[32]) {
   if (!ctx || !a || !b || !out_be) return BN256_EINVAL;
-  PRIMARY_SHARD(ctx);
-  int rc;
-  if ((rc = fr_range_check(a, a_off, n_a, a_stride)) || (rc = fr_range_check(b, b_off, n_b, b_stride))) return rc;
-  memset(out_be, 0, 32);
-  size_t n = std::min(n_a, n_b);  // the padded tail multiplies by zero
-  if (n == 0) return BN256_OK;
-  HIPCHK(hipSetDevice(ctx->device));
-  const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
-  const u32 nthreads = (u32)((n + per - 1) / per);
-  const u32 nblk = nblocks(nthreads, 256);
-  if ((rc = ws_reserve(ctx, WS_TMP, (size_t)nblk * sizeof(fr) + 64))) return rc;
-  uint8_t* d_out = (uint8_t*)ctx->ws[WS_TMP];
-  fr* partials = (fr*)(d_out + 64);
-  fr_arg mu;
-  memset(&mu, 0, sizeof mu);
-  if (mu_be) mu = fr_arg_canon(fr_arg_from_be(mu_be));
-  hipLaunchKernelGGL(k_fr_dot, dim3(nblk), dim3(256), 0, ctx->stream, (const uint8_t*)(a->d + a_off * 32),
-                     (u32)a_stride, (u32)n_a, (const uint8_t*)(b->d + b_off * 32), (u32)b_stride, (u32)n_b, (u32)n, per,
-                     mu, (u32)(mu_be != nullptr), partials);
-  hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, ctx->stream, (const fr*)partials, nblk, d_out);
-  HIPCHK(hipMemcpyAsync(out_be, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return BN256_OK;
+  return bn256_fr_dot_multi(ctx, 1, &a, &a_off, &a_stride, &n_a, &b, &b_off, &b_stride, &n_b, &mu_be, out_be);
 }
 
 extern "C" int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
@@ -1933,22 +2097,37 @@ extern "C" int bn256_msm_fr_multi_submit(bn256_ctx* ctx, int k, const bn256_base
   SINGLE_DEVICE_ONLY(ctx);
   *ticket = -1;
   HIPCHK(hipSetDevice(ctx->device));
-  int l = 0, rc;
-  while (l < BN256_ASYNC_LANES && ctx->pending[l]) l++;
-  if (l == BN256_ASYNC_LANES) return BN256_EBUSY;
-  if (!ctx->lane[l] && (rc = bn256_ctx_create(ctx->device, &ctx->lane[l]))) return rc;
-  bn256_ctx* lane = ctx->lane[l];
-  lane->tune_c = ctx->tune_c;
-  lane->tune_k = ctx->tune_k;
-  msm_pending* pend = new (std::nothrow) msm_pending();
-  if (!pend) return BN256_ENOMEM;
-  rc = fr_multi_enqueue(lane, k, b, off, stride, n, v, v_off, v_stride, scale_be, true, pend);
-  if (rc) {
-    (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
-    delete pend;
-    return rc;
+  int l, rc;
+  for (int i = 0; i < k; i++) {
+    if (!b[i] || !v[i]) return BN256_EINVAL;
+    if ((rc = range_check(b[i], off[i], n[i], stride[i])) || (rc = fr_range_check(v[i], v_off[i], n[i], v_stride[i]))) return rc;
   }
-  ctx->pending[l] = pend;
+  if ((rc = lane_acquire(ctx, &l))) return rc;
+  struct args_t {  // the caller's arrays are not ours after return
+    std::vector<const bn256_bases*> b;
+    std::vector<const bn256_frvec*> v;
+    std::vector<size_t> off, stride, n, v_off, v_stride;
+    std::vector<std::vector<uint8_t>> scale;
+    std::vector<const uint8_t*> sptr;
+  };
+  auto a = std::make_shared<args_t>();
+  for (int i = 0; i < k; i++) {
+    a->b.push_back(b[i]);
+    a->v.push_back(v[i]);
+    a->off.push_back(off[i]);
+    a->stride.push_back(stride[i]);
+    a->n.push_back(n[i]);
+    a->v_off.push_back(v_off[i]);
+    a->v_stride.push_back(v_stride[i]);
+    a->scale.emplace_back();
+    if (scale_be && scale_be[i]) a->scale.back().assign(scale_be[i], scale_be[i] + 32);
+  }
+  for (auto& sv : a->scale) a->sptr.push_back(sv.empty() ? nullptr : sv.data());
+  rc = lane_start(ctx, l, false, [a, k](bn256_ctx* lane, lane_ticket* t) -> int {
+    return bn256_msm_fr_multi(lane, k, a->b.data(), a->off.data(), a->stride.data(), a->n.data(), a->v.data(),
+                              a->v_off.data(), a->v_stride.data(), a->sptr.data(), t->xy);
+  });
+  if (rc) return rc;
   *ticket = l;
   return BN256_OK;
 }

@@ -840,15 +840,55 @@ Fr devDot(bn256_ctx* ctx, const DevFr& a, View va, const DevFr& b, View vb, cons
   chk(bn256_fr_dot(ctx, a.h, va.off, va.stride, va.len, b.h, vb.off, vb.stride, vb.len, mu ? mub : nullptr, out));
   return fr_from_be(out);
 }
-// vectorAdd(vectorMulOnScalar(v0, s0), vectorMulOnScalar(v1, s1)) on the halves of v (go/bppp/util.go:237-260)
-DevFr devFoldHalves(bn256_ctx* ctx, const DevFr& v, const Fr& s0, const Fr& s1) {
-  uint8_t b0[32], b1[32];
-  fr_to_be(b0, s0);
-  fr_to_be(b1, s1);
-  View e = evens(v.n), o = odds(v.n);
-  bn256_frvec* r = nullptr;
-  chk(bn256_fr_fold(ctx, v.h, e.off, e.len, v.h, o.off, o.len, 2, b0, b1, &r));
-  return DevFr(ctx, r);
+// k inner products in one device call (bn256_fr_dot_multi)
+struct DotArg {
+  const DevFr* a;
+  View va;
+  const DevFr* b;
+  View vb;
+  const Fr* mu;
+};
+void devDotMulti(bn256_ctx* ctx, const std::vector<DotArg>& d, Fr* out) {
+  const size_t k = d.size();
+  std::vector<const bn256_frvec*> a(k), b(k);
+  std::vector<size_t> ao(k), as(k), an(k), bo(k), bs(k), bn(k);
+  std::vector<std::vector<uint8_t>> mu(k);
+  std::vector<const uint8_t*> mup(k, nullptr);
+  std::vector<uint8_t> res(32 * k);
+  for (size_t i = 0; i < k; i++) {
+    a[i] = d[i].a->h; ao[i] = d[i].va.off; as[i] = d[i].va.stride; an[i] = d[i].va.len;
+    b[i] = d[i].b->h; bo[i] = d[i].vb.off; bs[i] = d[i].vb.stride; bn[i] = d[i].vb.len;
+    if (d[i].mu) {
+      mu[i].resize(32);
+      fr_to_be(mu[i].data(), *d[i].mu);
+      mup[i] = mu[i].data();
+    }
+  }
+  chk(bn256_fr_dot_multi(ctx, (int)k, a.data(), ao.data(), as.data(), an.data(), b.data(), bo.data(), bs.data(), bn.data(),
+                         mup.data(), res.data()));
+  for (size_t i = 0; i < k; i++) out[i] = fr_from_be(&res[32 * i]);
+}
+// three devFoldHalves in one device call (bn256_fr_fold_multi): c', l', n' of a WNLA round
+void devFoldHalves3(bn256_ctx* ctx, const DevFr& v0, const Fr& a0, const Fr& b0, const DevFr& v1, const Fr& a1,
+                    const Fr& b1, const DevFr& v2, const Fr& a2, const Fr& b2, DevFr& o0, DevFr& o1, DevFr& o2) {
+  const DevFr* v[3] = {&v0, &v1, &v2};
+  const Fr* sa[3] = {&a0, &a1, &a2};
+  const Fr* sb[3] = {&b0, &b1, &b2};
+  const bn256_frvec* h[3];
+  size_t eo[3], en[3], oo[3], on[3], st[3] = {2, 2, 2};
+  uint8_t ab[96], bb[96];
+  for (int i = 0; i < 3; i++) {
+    View e = evens(v[i]->n), o = odds(v[i]->n);
+    h[i] = v[i]->h;
+    eo[i] = e.off; en[i] = e.len; oo[i] = o.off; on[i] = o.len;
+    fr_to_be(ab + 32 * i, *sa[i]);
+    fr_to_be(bb + 32 * i, *sb[i]);
+  }
+  bn256_frvec* r[3] = {nullptr, nullptr, nullptr};
+  chk(bn256_fr_fold_multi(ctx, 3, h, eo, en, h, oo, on, st, ab, bb, r));
+  o0 = DevFr(ctx, r[0]);
+  o1 = DevFr(ctx, r[1]);
+  o2 = DevFr(ctx, r[2]);
 }
 // BP++ vectorPointScalarMul semantics on views (go/bppp/util.go:178-196): an empty view is the
 // identity, the shorter side decides the length (zero padding / truncation).
@@ -967,15 +1007,20 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
                                      {&G, G1, &n, n0, &roinv}});
     int tr = devMsmFusedSubmit(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
     lap(PF_MSM);
-    Fr vx = add(mul(devDot(ctx, n, n0, n, n1, &mu2), mul(fr_from_u64(2), roinv)),
-                add(devDot(ctx, c, c0, l, l1, nullptr), devDot(ctx, c, c1, l, l0, nullptr)));
-    Fr vr = add(devDot(ctx, n, n1, n, n1, &mu2), devDot(ctx, c, c1, l, l1, nullptr));
+    // the round's five inner products (docs_test.go:1297-1311) in one call: one wait, one copy
+    Fr d5[5];
+    devDotMulti(ctx, {{&n, n0, &n, n1, &mu2}, {&c, c0, &l, l1, nullptr}, {&c, c1, &l, l0, nullptr},
+                      {&n, n1, &n, n1, &mu2}, {&c, c1, &l, l1, nullptr}}, d5);
+    Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv)), add(d5[1], d5[2]));
+    Fr vr = add(d5[3], d5[4]);
     lap(PF_DOT);
+    Point gx = scalarMult(g, vx), gr = scalarMult(g, vr);  // under the MSMs, which the lanes' threads are running
+    lap(PF_HOSTPT);
     Point mx = devMsmWait(ctx, tx);
     Point mr = devMsmWait(ctx, tr);
     lap(PF_MSM);
-    Point X = pointAdd(scalarMult(g, vx), mx);
-    Point R = pointAdd(scalarMult(g, vr), mr);
+    Point X = pointAdd(gx, mx);
+    Point R = pointAdd(gr, mr);
     lap(PF_HOSTPT);
     res.X.push_back(X);
     res.R.push_back(R);
@@ -984,23 +1029,23 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     fr_to_be(oneb, kFrOne);
     fr_to_be(yb, y);
     fr_to_be(rob, ro);
-    // G's fold (a full-length chain: ro is a 256-bit scalar) goes to a lane; H's fold, the three
-    // scalar-vector folds and the host's C' run meanwhile
+    // both generator folds go to lanes (G's is a full-length chain: ro is a 256-bit scalar); the three
+    // scalar-vector folds (one call) and the host's C' run meanwhile
     bn256_bases *hn = nullptr, *gn = nullptr;
-    int tg = -1;
+    int tg = -1, th = -1;
     chk(bn256_fold2_submit(ctx, G.h, G0.off, G0.len, G.h, G1.off, G1.len, 2, rob, yb, &gn, &tg));
     DevPoints Gn(ctx, gn);
-    chk(bn256_fold2(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn));
+    chk(bn256_fold2_submit(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn, &th));
     DevPoints Hn(ctx, hn);
     lap(PF_PTFOLD);
-    DevFr c_ = devFoldHalves(ctx, c, kFrOne, y);
-    DevFr l_ = devFoldHalves(ctx, l, kFrOne, y);
-    DevFr n_ = devFoldHalves(ctx, n, roinv, y);
+    DevFr c_, l_, n_;
+    devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
     lap(PF_FRFOLD);
     Point C_ = pointAdd(C, scalarMult(X, y));
     C_ = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
     lap(PF_HOSTPT);
     chk(bn256_fold_wait(ctx, tg));
+    chk(bn256_fold_wait(ctx, th));
     lap(PF_PTFOLD);
     G = std::move(Gn);
     H = std::move(Hn);

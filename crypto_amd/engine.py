@@ -317,6 +317,30 @@ class Engine:
         self._chk(self.lib.bn256_fr_dot(self.ctx, a.h, a_off, a_stride, n_a, b.h, b_off, b_stride, n_b, mub, out))
         return int.from_bytes(out.raw, "big")
 
+    def fr_dot_multi(self, items: Sequence[tuple]) -> list[int]:
+        """items: (a, a_off, a_stride, n_a, b, b_off, b_stride, n_b[, mu]) -- k inner products, one device call."""
+        k = len(items)
+        m = max(k, 1)
+        col = lambda j: (C.c_size_t * m)(*[it[j] for it in items])  # noqa: E731
+        mus = [(int(it[8]).to_bytes(32, "big") if len(it) > 8 and it[8] is not None else None) for it in items]
+        out = C.create_string_buffer(32 * m)
+        self._chk(self.lib.bn256_fr_dot_multi(self.ctx, k, (C.c_void_p * m)(*[it[0].h for it in items]), col(1), col(2), col(3),
+                                              (C.c_void_p * m)(*[it[4].h for it in items]), col(5), col(6), col(7),
+                                              (C.c_char_p * m)(*mus), out))
+        return [int.from_bytes(out.raw[32 * j:32 * j + 32], "big") for j in range(k)]
+
+    def fr_fold_multi(self, items: Sequence[tuple]) -> list[FrVec]:
+        """items: (a, a_off, n_a, b, b_off, n_b, s_a, s_b, stride) -- k folds, one device call."""
+        k = len(items)
+        m = max(k, 1)
+        col = lambda j: (C.c_size_t * m)(*[it[j] for it in items])  # noqa: E731
+        outs = (C.c_void_p * m)()
+        self._chk(self.lib.bn256_fr_fold_multi(self.ctx, k, (C.c_void_p * m)(*[it[0].h for it in items]), col(1), col(2),
+                                               (C.c_void_p * m)(*[it[3].h for it in items]), col(4), col(5), col(8),
+                                               b"".join(int(it[6]).to_bytes(32, "big") for it in items),
+                                               b"".join(int(it[7]).to_bytes(32, "big") for it in items), outs))
+        return [FrVec(self, C.c_void_p(outs[j])) for j in range(k)]
+
     def msm_fr(self, bases: Bases, off: int, stride: int, n: int, v: FrVec, v_off: int = 0, v_stride: int = 1) -> bytes:
         out = C.create_string_buffer(64)
         self._chk(self.lib.bn256_msm_fr(self.ctx, bases.h, off, stride, n, v.h, v_off, v_stride, out))

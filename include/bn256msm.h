@@ -105,13 +105,15 @@ int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size
 /* bn256_msm_dev split in two, for callers with several independent commitments to make -- A and S
  * (go/bp/main.go:89,95), L and R of an inner-product level (go/bp/main.go:340-341), the WNLA
  * round's X and R (go/bppp/docs_test.go:1312-1320) -- none of which needs another's result.  The reference computes
- * them one after the other on its single goroutine; here submit returns once the pipeline is
- * enqueued on one of 3 internal lanes (own stream and workspaces), and wait blocks
- * for that lane, runs the host tail and returns the same bytes bn256_msm_dev would.  The bucket
- * reduction and host tail of one call then hide under the accumulation of the next (+9 % points/s at
- * 2^20 points).  The scalars must stay untouched, and the bases handle alive, until the matching wait; a fourth submit without a
- * wait returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One thread per context, as
- * everywhere in this library. */
+ * them one after the other on its single goroutine; here submit hands the whole call (enqueueing the
+ * pipeline, waiting for it, the host tail) to one of 3 internal lanes -- each a context of its own
+ * (stream, workspaces) with a host thread of its own -- and returns at once; wait blocks until that
+ * lane has finished and returns the same bytes bn256_msm_dev would.  The calls of the lanes overlap
+ * on the GPU (+9 % points/s at 2^20 points) and their host work runs beside the caller's.  Argument
+ * errors are reported by submit; errors of the call itself (BN256_ENOMEM, BN256_EHIP) by wait.  The
+ * scalars must stay untouched, and the bases handle alive, until the matching wait; a fourth submit
+ * without a wait returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One caller thread
+ * per context, as everywhere in this library. */
 int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                      int* ticket);
 int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]);
@@ -220,6 +222,19 @@ int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t n_a
 int bn256_fr_dot(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off, size_t a_stride, size_t n_a,
                  const bn256_frvec* b, size_t b_off, size_t b_stride, size_t n_b, const uint8_t* mu_be,
                  uint8_t out_be[32]);
+
+/* k folds / k inner products as ONE call: the kernels are enqueued back to back and the host waits once
+ * (and, for the products, copies k * 32 result bytes once).  A WNLA round needs five inner products
+ * for v_x, v_r (go/bppp/docs_test.go:1297-1311) and three vector folds c', l', n' (:1327-1334); a wait
+ * and a 32-byte copy per product was 0.2 ms of every round.  Arrays have k entries; s_a_be / s_b_be are
+ * k * 32 bytes; mu_be is NULL or an array whose entries may be NULL (plain vectorMul); out_be is
+ * k * 32 bytes.  Semantics per entry are those of bn256_fr_fold / bn256_fr_dot. */
+int bn256_fr_fold_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off, const size_t* n_a,
+                        const bn256_frvec* const* b, const size_t* b_off, const size_t* n_b, const size_t* stride,
+                        const uint8_t* s_a_be, const uint8_t* s_b_be, bn256_frvec** out);
+int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off, const size_t* a_stride,
+                       const size_t* n_a, const bn256_frvec* const* b, const size_t* b_off, const size_t* b_stride,
+                       const size_t* n_b, const uint8_t* const* mu_be, uint8_t* out_be);
 
 /* bn256_msm over views: sum_i v[v_off + i*v_stride] * b[off + i*stride], scalars never leave
  * the device (vectorPointScalarMul on reducePoints / reduceVector halves). */

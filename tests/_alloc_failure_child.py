@@ -47,7 +47,8 @@ out["big_frvec"] = code_of(lambda: eng.fr_random(4, 1 << 23))
 hb = eng.random_bases(5, 1 << 18)
 vb = eng.fr_random(6, 1 << 18)
 out["big_workspace_blocking"] = code_of(lambda: eng.msm_dev(hb, vb.device_ptr(), 1 << 18))
-out["big_workspace_submit"] = [code_of(lambda: eng.msm_submit(hb, vb.device_ptr(), 1 << 18)) for _ in range(5)]
+# a submitted call reports it at the wait (the lane's thread reserves the workspaces), and frees its lane
+out["big_workspace_submit"] = [code_of(lambda: eng.msm_wait(eng.msm_submit(hb, vb.device_ptr(), 1 << 18))) for _ in range(5)]
 # the context, its lanes and its pool are as usable as before
 out["small_after"] = eng.msm(h, sraw) == want
 v = eng.fr_upload(sraw)

@@ -198,3 +198,33 @@ def test_fused_multi_segment_msm(eng, orc):
     seg = [(Hb, 0, 2, big // 2, lb, 1, 2), (Hb, 1, 2, big // 2, lb, 0, 2, ro)]
     t1, t2 = eng.msm_fr_multi_submit(seg), eng.msm_fr_multi_submit(seg[:1])
     assert eng.msm_wait(t1) == eng.msm_fr_multi(seg) and eng.msm_wait(t2) == eng.msm_fr_multi(seg[:1])
+
+
+def test_multi_dot_and_multi_fold_match_the_single_calls(eng):
+    """bn256_fr_dot_multi / bn256_fr_fold_multi: the five inner products and three folds of a WNLA round
+    (go/bppp/docs_test.go:1297-1311,1327-1334) as one call each -- entry by entry the single calls'
+    results, including ragged even / odd views, an empty product and plain next to weighted ones."""
+    rng = random.Random(77)
+    for nl, nn in ((9, 5), (8, 4), (1001, 500), (2, 1)):
+        l, n, c = _vals(rng, nl), _vals(rng, nn), _vals(rng, nl)
+        mu2, y, roinv = rng.randrange(1, N), rng.randrange(1, N), rng.randrange(1, N)
+        hl, hn, hc = eng.fr_upload(l), eng.fr_upload(n), eng.fr_upload(c)
+        ev = lambda m: (0, 2, (m + 1) // 2)              # noqa: E731  reduceVector halves as (off, stride, len)
+        od = lambda m: (1 if m > 1 else 0, 2, m // 2)   # noqa: E731
+        items = [(hn, *ev(nn), hn, *od(nn), mu2), (hc, *ev(nl), hl, *od(nl)), (hc, *od(nl), hl, *ev(nl)),
+                 (hn, *od(nn), hn, *od(nn), mu2), (hc, *od(nl), hl, *od(nl), None), (hl, 0, 1, 0, hl, 0, 1, 0)]
+        got = eng.fr_dot_multi(items)
+        assert got == [eng.fr_dot(*it[:8], mu=(it[8] if len(it) > 8 else None)) for it in items]
+        l0, l1, n0, n1, c0, c1 = l[0::2], l[1::2], n[0::2], n[1::2], c[0::2], c[1::2]
+        assert got[0] == ref.weight_vector_mul(n0, n1, mu2) and got[1] == ref.vector_mul_bppp(c0, l1)
+        assert got[5] == 0
+        folds = [(hc, ev(nl)[0], ev(nl)[2], hc, od(nl)[0], od(nl)[2], 1, y, 2),
+                 (hl, ev(nl)[0], ev(nl)[2], hl, od(nl)[0], od(nl)[2], 1, y, 2),
+                 (hn, ev(nn)[0], ev(nn)[2], hn, od(nn)[0], od(nn)[2], roinv, y, 2)]
+        outs = eng.fr_fold_multi(folds)
+        for f, o in zip(folds, outs):
+            single = eng.fr_fold(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], stride=2)
+            assert o.download() == single.download()
+        want_n = ref.vector_add_bppp(ref.vector_mul_on_scalar(n0, roinv), ref.vector_mul_on_scalar(n1, y))
+        assert outs[2].download() == want_n
+    assert eng.fr_dot_multi([]) == [] and eng.fr_fold_multi([]) == []
