@@ -156,6 +156,7 @@ struct bn256_bases {
   size_t n;       // points per level
   int levels;     // 1, or W when precomputed
   int c;          // window bits the levels were built for (0 when levels == 1)
+  u32 top_scale;  // the top level holds (1 / top_scale) * 2^(c (W-1)) * P and its digits are multiplied by top_scale
   size_t cap;     // bytes of the block behind d (pool)
   int dev;
   // handle of a multi-device context (bn256_ctx_create_multi): d == nullptr, shard s holds the
@@ -166,7 +167,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_BUCKETS2, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_COUNT };
 
 #define BN256_ASYNC_LANES 3
 struct bn256_ctx {
@@ -188,6 +189,10 @@ struct bn256_ctx {
   u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy), then the
                     // 1024 group totals of the two-pass sort: everything a pass needs zeroed, one memset
   u32* h_err;       // pinned
+  u32* d_flags;     // MSM_FLAG_* of the call in flight (kernels.cuh); h_flags: its pinned copy
+  u32* h_flags;
+  int force_split;  // enqueue the split-sort kernels (set after a call met an oversized group, cleared after one that did not)
+  int used_split;   // whether the pipeline enqueued last had them
   // bn256_msm_submit / bn256_msm_wait: each lane is a whole child context (own stream, workspaces,
   // pinned result buffer) on the same device, created on first use
   bn256_ctx* lane[BN256_ASYNC_LANES];
@@ -283,6 +288,8 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->d_err) (void)hipFree(ctx->d_err);
   if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -293,21 +300,26 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
 static int ctx_init(bn256_ctx* ctx) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
-  for (int i = 0; i < 2; i++) {
-    hipError_t e = i == 0 ? pool::dev_malloc((void**)&ctx->d_err, 256)
-                          : pool::dev_malloc((void**)&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32));
+  for (int i = 0; i < 3; i++) {
+    hipError_t e = i == 0   ? pool::dev_malloc((void**)&ctx->d_err, 256)
+                   : i == 1 ? pool::dev_malloc((void**)&ctx->d_flags, 256)
+                            : pool::dev_malloc((void**)&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32));
     if (e != hipSuccess) {
       ctx_note_hip(e, __LINE__);
       return e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
     }
   }
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
+  HIPCHK(hipHostMalloc(&ctx->h_flags, 256));
+  ctx->h_flags[0] = 0;
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
   // the sort kernels' dynamic LDS above 48 KiB (per function and device; set here so that no MSM
   // call carries set-up work)
-  HIPCHK(hipFuncSetAttribute((const void*)k_part, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_part<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_part<20, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_group_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_group_sort_tl, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_tile_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   return scratch_resolve(ctx->device);  // this device's copy of the static scratch array
@@ -410,6 +422,10 @@ static int pick_c(const bn256_ctx* ctx, size_t n, bool precomp) {
   // whole 2^15-bucket histogram in LDS and leaves a full-width top window (255 = 15*16 + 15);
   // the smaller choices are the ones whose top window is not a few-bucket hot spot.
   int lg = ilog2_floor(n ? n : 1);
+  // from 2^20 points a table of 13 levels of 20-bit windows (2^19 buckets, DESIGN.md "wide windows"):
+  // 19 % fewer additions; its longer bucket reduction is paid once per call, so the gain grows with
+  // the number of passes (2^20: +2 %, 2^21: +5..10 %, 2^24: +13 %)
+  if (precomp && lg >= 20) return 20;
   if (precomp) return lg >= 13 ? 16 : (lg >= 9 ? 13 : 10);
   return lg >= 17 ? 16 : (lg >= 15 ? 10 : 8);
 }
@@ -424,6 +440,7 @@ static bn256_bases* bases_alloc(size_t n, int levels, int c, int* rc) {
   b->n = n;
   b->levels = levels;
   b->c = c;
+  b->top_scale = 1;
   b->d = nullptr;
   size_t bytes = std::max<size_t>(1, n) * (size_t)levels * sizeof(aff_mem);
   hipError_t e = pool::alloc((void**)&b->d, bytes, &b->cap, &b->dev);
@@ -453,6 +470,52 @@ static void normalize_into(bn256_ctx* ctx, const xyzz_mem* in, aff_mem* out, siz
                      (i32*)ctx->ws[WS_PARTIALS], (u32)n, B);
 }
 
+// With wide windows the top window is much narrower than the others (c = 20: 13 windows, the top one
+// holds bits 240..254 of a scalar below n/2, values <= 18395 of 2^19): its 2^20 digits per 2^20 points
+// would all land in the first 3.5 % of the buckets and make the sort's first groups three times as
+// large as the rest.  The top table level is therefore stored as (1 / s) * 2^(c (W-1)) * P and the top
+// digit multiplied by s = floor(2^(c-1) / 18395): the same sum, with the top window's entries spread
+// over the whole bucket range.  s = 1 (nothing changes) for every other window width.
+static u32 top_scale_for(int c) {
+  if (c != 20) return 1;
+  const int W = windows_for(c);
+  // (n - 1) / 2 >> (c (W - 1)), + 1 for the carry out of the window below
+  static const uint64_t half[4] = {0x0d177a2dabd63930ULL, 0x9746c7097c159c92ULL, 0xd537f65c30c26e10ULL,
+                                   0x47da80f1a551c3fcULL};
+  const int sh = c * (W - 1);
+  uint64_t top = half[sh >> 6] >> (sh & 63);
+  if ((sh & 63) && (sh >> 6) < 3) top |= half[(sh >> 6) + 1] << (64 - (sh & 63));
+  top += 1;
+  return (u32)((1ull << (c - 1)) / top);
+}
+// 1 / s mod n for a small s, 32 bytes big-endian: (n t + 1) / s with n t = -1 (mod s)
+static void small_inverse_mod_n(uint8_t out_be[32], u32 s_) {
+  static const uint64_t nw[4] = {0x1a2ef45b57ac7261ULL, 0x2e8d8e12f82b3924ULL, 0xaa6fecb86184dc21ULL,
+                                 0x8fb501e34aa387f9ULL};
+  const uint64_t sdiv = s_;
+  uint64_t nmod = 0;
+  for (int i = 3; i >= 0; i--) nmod = (uint64_t)((((unsigned __int128)nmod << 64) | nw[i]) % sdiv);
+  uint64_t t = 0;
+  while ((nmod * t + 1) % sdiv) t++;
+  uint64_t prod[5];
+  unsigned __int128 cy = 1;
+  for (int i = 0; i < 4; i++) {
+    cy += (unsigned __int128)nw[i] * t;
+    prod[i] = (uint64_t)cy;
+    cy >>= 64;
+  }
+  prod[4] = (uint64_t)cy;
+  uint64_t q[5], rem = 0;
+  for (int i = 4; i >= 0; i--) {
+    unsigned __int128 cur = ((unsigned __int128)rem << 64) | prod[i];
+    q[i] = (uint64_t)(cur / sdiv);
+    rem = (uint64_t)(cur % sdiv);
+  }
+  hostg1::be_store(out_be, q);
+}
+static int fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32 stride, const uint8_t s_lo_be[32],
+                       const uint8_t s_hi_be[32], u32 n_lo, u32 n_hi, xyzz_mem** xs_out);
+
 static int bases_precompute(bn256_ctx* ctx, bn256_bases* b) {
   xyzz_mem* xs;
   int rc = xyzz_scratch(ctx, b->n, &xs);
@@ -461,6 +524,15 @@ static int bases_precompute(bn256_ctx* ctx, bn256_bases* b) {
     hipLaunchKernelGGL(k_precompute_level, dim3(nblocks(b->n, 256)), dim3(256), 0, ctx->stream,
                        b->d + (size_t)(l - 1) * b->n, xs, (u32)b->n, (u32)b->c);
     normalize_into(ctx, xs, b->d + (size_t)l * b->n, b->n);
+  }
+  b->top_scale = top_scale_for(b->c);
+  if (b->top_scale > 1) {  // top level *= 1 / top_scale: one scalar for every point, in place
+    uint8_t inv_be[32];
+    static const uint8_t zero[32] = {0};
+    small_inverse_mod_n(inv_be, b->top_scale);
+    aff_mem* top = b->d + (size_t)(b->levels - 1) * b->n;
+    if ((rc = fold_points(ctx, top, top, 1u, inv_be, zero, (u32)b->n, 0u, &xs))) return rc;
+    normalize_into(ctx, xs, top, b->n);
   }
   HIPCHK(hipGetLastError());
   return BN256_OK;
@@ -694,7 +766,11 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   const u32 nsets = precomp ? 1u : (u32)W;
   const size_t nbt = (size_t)nb * nsets;
   const u32 q = (u32)(c - 1);
-  const size_t chunk = ctx->msm_chunk ? ctx->msm_chunk : MSM_CHUNK;
+  // c = 20 ("wide" fixed-base path): 13 windows instead of 16, one set of 2^19 buckets; its sort keeps
+  // tile-local 11-bit indices in the records, which limits a pass to 2^20 points
+  const bool wide = precomp && c == 20;
+  const size_t chunk_max = wide ? ((size_t)1 << 20) : ((size_t)1 << 30);
+  const size_t chunk = std::min(ctx->msm_chunk ? ctx->msm_chunk : MSM_CHUNK, chunk_max);
   // the passes: every term in sub-ranges of <= chunk points (table-less: the one term, one pass)
   size_t npasses = 0, nmax = 0;
   for (int i = 0; i < nsrc; i++) {
@@ -724,8 +800,9 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   u32 ibits = 0, wbits = 0;
   while (((size_t)1 << ibits) < nmax) ibits++;
   while ((1u << wbits) < (u32)W) wbits++;
-  const u32 LB2 = precomp ? (entries_max <= (1ull << 24) ? 6u : 5u) : 9u;  // log2 keys per group
-  const u32 NH2 = LB2 <= 6 ? 16u : 4u;                                      // histogram copies in pass B
+  const u32 LB2 = wide ? 10u : precomp ? (entries_max <= (1ull << 24) ? 6u : 5u) : 9u;  // log2 keys per group
+  const u32 NH2 = wide ? 2u : LB2 <= 6 ? 16u : 4u;                                       // histogram copies in pass B
+  const u32 cap2 = wide ? SORT20_CAP : SORT2_CAP;  // records of one group that pass B sorts inside LDS
   const u32 G2 = (u32)(nbt >> LB2);
   const u32 key_stride = precomp ? 0u : nb;
   auto tiles2_for = [&](size_t m) -> u32 {
@@ -736,25 +813,26 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   // a pass uses it only with >= 2^18 points with a table, 2^19 without: below, the fixed costs of the
   // 2^9..2^10 groups dominate
   const size_t two_min = (size_t)1 << (precomp ? 18 : 19);
-  const bool two_pass = c == 16 && nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
-                        nmax >= two_min && entries_max <= (unsigned long long)G2 * 32768 &&
-                        (precomp ? wbits + ibits + 1 + LB2 <= 32 : ibits + 1 + LB2 <= 32);
+  const bool two_pass =
+      wide ? (!ctx->sort1 && G2 == 512 && tiles2_max <= 1024 && nmax >= two_min && nmax <= ((size_t)1 << 20) &&
+              entries_max <= (unsigned long long)G2 * 32768)
+           : (c == 16 && nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
+              nmax >= two_min && entries_max <= (unsigned long long)G2 * 32768 &&
+              (precomp ? wbits + ibits + 1 + LB2 <= 32 : ibits + 1 + LB2 <= 32));
   const size_t lds_part = ((size_t)2 * G2 + std::max<size_t>((size_t)16 * G2, SORT2_TCAP)) * 4;
-  const size_t lds_gsort = ((size_t)(NH2 + 1) * (1u << LB2) + 2048 + SORT2_CAP) * 4;
+  const size_t lds_gsort = wide ? ((size_t)(NH2 + 1) * (1u << LB2) + 3072 + SORT20_CAP) * 4
+                                : ((size_t)(NH2 + 1) * (1u << LB2) + 2048 + SORT2_CAP) * 4;
+  // WS_RANK: the records of pass A (one SORT2_TCAP block per tile), or the per-tile histograms of the
+  // single-pass LDS sort (also for a short last pass of a two-pass call), or the ranks of the
+  // global-atomic sort -- whichever this call's passes may need
+  size_t rank_bytes = use_lds ? (size_t)nsets * want_tiles * nb * 4 : (size_t)entries_max * 4;
   if (two_pass) {
-    // records of pass A (one SORT2_TCAP block per tile); also the per-tile histograms of a short last
-    // pass that falls back to the single-pass sort
-    if ((rc = ws_reserve(ctx, WS_RANK, std::max<size_t>((size_t)tiles2_max * SORT2_TCAP * 4,
-                                                        (size_t)nsets * want_tiles * nb * 4))))
-      return rc;
+    rank_bytes = std::max(rank_bytes, (size_t)tiles2_max * SORT2_TCAP * 4);
     if ((rc = ws_reserve(ctx, WS_GBASE, (size_t)tiles2_max * (G2 + 1) * 4))) return rc;  // loc[tile][0..G]
-    if ((rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nbt * SORT2_S + 1) * 4))) return rc;
+    // only the split-sort kernels use it (skewed scalars; see `split` below)
+    if (ctx->force_split && (rc = ws_reserve(ctx, WS_SUBHIST, ((size_t)nbt * SORT2_S + 1) * 4))) return rc;
   }
-  if (use_lds) {
-    if (!two_pass && (rc = ws_reserve(ctx, WS_RANK, (size_t)nsets * want_tiles * nb * 4))) return rc;  // per-tile histograms
-  } else {
-    if ((rc = ws_reserve(ctx, WS_RANK, entries_max * 4))) return rc;
-  }
+  if ((rc = ws_reserve(ctx, WS_RANK, rank_bytes))) return rc;
   // chunk length K of the accumulation kernel and its thread count for a pass of m points
   auto pick_k = [&](size_t m) -> u32 {
     unsigned long long e = (unsigned long long)m * W;
@@ -783,8 +861,8 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   if ((rc = ws_reserve(ctx, WS_OFFSETS, (nbt + 2) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BLOCKSUM, (size_t)(nscan_max + 1) * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_BUCKETS, nbt * sizeof(xyzz_mem)))) return rc;
-  if (nchunks > 1 && (rc = ws_reserve(ctx, WS_BUCKETS2, nbt * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * Tmax * sizeof(xyzz_mem)))) return rc;
+  if ((rc = ws_reserve(ctx, WS_LASTB, Tmax * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_PACK, npack * 32 * 4))) return rc;
   if (npack * 32 * 4 > ctx->h_pack_cap) return BN256_EINVAL;
 
@@ -795,12 +873,21 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   u32* sval = (u32*)ctx->ws[WS_SVAL];
   u32* blocksum = (u32*)ctx->ws[WS_BLOCKSUM];
   xyzz_mem* buckets = (xyzz_mem*)ctx->ws[WS_BUCKETS];
-  xyzz_mem* sum_buckets = nchunks > 1 ? (xyzz_mem*)ctx->ws[WS_BUCKETS2] : buckets;
+  xyzz_mem* sum_buckets = buckets;  // later passes add into the same array (k_accumulate's add_prev)
   xyzz_mem* partials = (xyzz_mem*)ctx->ws[WS_PARTIALS];
   u32* d_pack = (u32*)ctx->ws[WS_PACK];
   u32* heavy_count = ctx->d_heavy;
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
+  // The split-sort kernels (groups larger than pass B's LDS capacity: skewed scalars) are three
+  // launches that do nothing for ordinary inputs.  They are enqueued only while ctx->force_split is
+  // set; without them an oversized group raises MSM_FLAG_OVERSIZED, the accumulation kernels then
+  // stand down and msm_finish asks for the call to be repeated with them (and keeps them on until a
+  // call sees no oversized group).  flags[0]: oversized and unhandled; flags[1]: oversized, handled.
+  const bool split = ctx->force_split != 0;
+  ctx->used_split = split;
+  u32* d_flags = ctx->d_flags;
+  HIPCHK(hipMemsetAsync(d_flags, 0, 8, s));
 
   size_t ch = 0;  // running pass number over all terms
   for (int si = 0; si < nsrc; si++) {
@@ -808,6 +895,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
    if (!t.n) continue;
    const bn256_bases* b = t.b;
    const size_t stride = t.stride, sc_stride = t.sc_stride;
+   const u32 top_scale = precomp ? b->top_scale : 1u;
    const size_t np_t = (precomp && t.n > chunk) ? (t.n + chunk - 1) / chunk : 1, len_t = np_t > 1 ? chunk : t.n;
    for (size_t cj = 0; cj < np_t; cj++, ch++) {
     const size_t n_ch = std::min(len_t, t.n - cj * len_t);
@@ -841,31 +929,44 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       u32* loc = (u32*)ctx->ws[WS_GBASE];
       u32* subhist = (u32*)ctx->ws[WS_SUBHIST];
       const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
-      hipLaunchKernelGGL(k_part, dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W, (u32)sc_stride, G2,
-                         LB2, ibits, key_stride, gtotal, loc, rank);
+      if (wide)
+        hipLaunchKernelGGL((k_part<20, true>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W, (u32)sc_stride,
+                           G2, LB2, ibits, key_stride, top_scale, gtotal, loc, rank);
+      else
+        hipLaunchKernelGGL((k_part<16, false>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W,
+                           (u32)sc_stride, G2, LB2, ibits, key_stride, top_scale, gtotal, loc, rank);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
       HIPCHK(hipEventRecord(ctx->ev[2], s));
-      hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
-                         (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets,
-                         sval);
-      // groups too large for LDS (skewed scalars): split over SORT2_S workgroups; no-ops otherwise
-      hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), (size_t)4 * (1u << LB2) * 4, s, (const u32*)rank,
-                         (const u32*)loc, (const u32*)gtotal, G2, TS, LB2, subhist);
-      hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(1024), 0, s, (const u32*)gtotal, LB2, subhist, offsets);
-      hipLaunchKernelGGL(k_group_place, dim3(G2 * SORT2_S), dim3(256), (size_t)(1u << LB2) * 4, s, (const u32*)rank,
-                         (const u32*)loc, (const u32*)gtotal, (const u32*)subhist, G2, TS, LB2, ibits, (u32)off_ch,
-                         (u32)stride, (u32)b->n, sval);
+      const u32 init_inf = ch == 0 ? 1u : 0u;  // buckets without entries: infinity on the call's first pass
+      u32* oversized = d_flags + (split ? 1 : 0);
+      if (wide)
+        hipLaunchKernelGGL(k_group_sort_tl, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
+                           (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval,
+                           buckets, init_inf, oversized);
+      else
+        hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
+                           (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets,
+                           sval, buckets, init_inf, oversized);
+      if (split) {  // groups too large for LDS (skewed scalars): split over SORT2_S workgroups each
+        hipLaunchKernelGGL(k_group_count, dim3(G2 * SORT2_S), dim3(256), (size_t)4 * (1u << LB2) * 4, s, (const u32*)rank,
+                           (const u32*)loc, (const u32*)gtotal, G2, TS, LB2, cap2, subhist);
+        hipLaunchKernelGGL(k_group_subscan, dim3(G2), dim3(1024), 0, s, (const u32*)gtotal, LB2, cap2, subhist, offsets,
+                           buckets, init_inf);
+        hipLaunchKernelGGL(k_group_place, dim3(G2 * SORT2_S), dim3(256), (size_t)(1u << LB2) * 4, s, (const u32*)rank,
+                           (const u32*)loc, (const u32*)gtotal, (const u32*)subhist, G2, TS, LB2, ibits, (u32)off_ch,
+                           (u32)stride, (u32)b->n, cap2, (u32)wide, sval);
+      }
     } else {
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
-                         (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
-                         (const u32*)nullptr, (u32*)nullptr);
+                         (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, top_scale,
+                         hist, (const u32*)nullptr, (u32*)nullptr);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
       hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
     } else {
       HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
       hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
-                         (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank,
+                         (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, top_scale, counts, rank,
                          (const u32*)nullptr, (u32*)nullptr);
       HIPCHK(hipEventRecord(ctx->ev[1], s));
     }
@@ -874,31 +975,34 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     HIPCHK(hipEventRecord(ctx->ev[2], s));
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
-                         (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, hist,
-                         (const u32*)offsets, sval);
+                         (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, top_scale,
+                         hist, (const u32*)offsets, sval);
     } else {
       hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
-                         (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, counts, rank,
+                         (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, top_scale, counts, rank,
                          (const u32*)offsets, sval);
     }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], s));
     // 128-thread workgroups: the same single round of waves, placed and retired in finer units
     // (measured 1.051 -> 1.031 ms at 2^20; 64 threads the same, limiting residency by LDS slower)
+    const u32 add_prev = ch > 0 ? 1u : 0u;  // later passes of the call add into the first pass's bucket sums
+    // the fix-up by chunk boundaries when there are fewer chunks than buckets (the 2^19-bucket path; its
+    // empty buckets were initialised by the two-pass sort), by buckets otherwise
+    const bool by_chunks = two && nbt > T;
+    u32* lastb = by_chunks ? (u32*)ctx->ws[WS_LASTB] : (u32*)nullptr;
     hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                       (const u32*)offsets, (u32)nbt, K, buckets, partials);
+                       (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
     HIPCHK(hipEventRecord(ctx->ev[4], s));
-    hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
-                       (const xyzz_mem*)partials, heavy_count, heavy_list);
+    if (by_chunks)
+      hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(T * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K,
+                         (const u32*)lastb, buckets, (const xyzz_mem*)partials, heavy_count, heavy_list,
+                         (const u32*)d_flags);
+    else
+      hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K,
+                         add_prev, buckets, (const xyzz_mem*)partials, heavy_count, heavy_list, (const u32*)d_flags);
     hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
                        heavy_count, (const u32*)heavy_list, (xyzz_mem*)ctx->ws[WS_HEAVYTMP]);
-    if (nchunks > 1) {
-      if (ch == 0)
-        HIPCHK(hipMemcpyAsync(sum_buckets, buckets, nbt * sizeof(xyzz_mem), hipMemcpyDeviceToDevice, s));
-      else
-        hipLaunchKernelGGL(k_add_buckets, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, sum_buckets,
-                           (const xyzz_mem*)buckets, (u32)nbt);
-    }
     HIPCHK(hipEventRecord(ctx->ev[5], s));
     HIPCHK(hipGetLastError());  // a failed launch is reported with its own pass, not after all of them
     if (ch + 1 < nchunks && !hold_stream) {  // per-pass phase times; the last pass is read after the reduction
@@ -914,13 +1018,19 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   }
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
-    hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, sum_buckets, nsets, nb, l);
+    if (threads >= ((size_t)1 << 17)) {  // a level of that many independent additions is throughput work: lane per addition
+      // whole waves per SIMD (1024 SIMDs x 64 lanes): three while the level fits them, else two and a grid-stride loop
+      const size_t launch = threads <= 196608 ? threads : 131072;
+      hipLaunchKernelGGL(k_fold_lane, dim3(nblocks(launch, 256)), dim3(256), 0, s, sum_buckets, nsets, nb, l);
+    } else
+      hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, sum_buckets, nsets, nb, l);
   }
   hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)sum_buckets, nsets, nb, q,
                      d_pack);
   HIPCHK(hipEventRecord(ctx->ev[6], s));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, npack * 32 * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(ctx->h_flags, d_flags, 8, hipMemcpyDeviceToHost, s));
   pend->empty = false;
   pend->c = c;
   pend->q = q;
@@ -928,7 +1038,9 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   return BN256_OK;
 }
 
-// Waits for the pipeline and runs the host tail; returns the sum as a host point.
+// Waits for the pipeline and runs the host tail; returns the sum as a host point.  MSM_RETRY (internal,
+// never leaves the library): the caller enqueues the same call again.
+#define MSM_RETRY 1
 static int msm_finish(bn256_ctx* ctx, const msm_pending* pend, hostg1::Pt* result) {
   using namespace hostg1;
   *result = infinity();
@@ -936,6 +1048,11 @@ static int msm_finish(bn256_ctx* ctx, const msm_pending* pend, hostg1::Pt* resul
   const int c = pend->c;
   const u32 q = pend->q, nsets = pend->nsets;
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_flags[0] & MSM_FLAG_OVERSIZED) {  // see msm_enqueue_srcs: repeat with the split-sort kernels
+    ctx->force_split = 1;
+    return MSM_RETRY;
+  }
+  if (ctx->used_split && !ctx->h_flags[1]) ctx->force_split = 0;  // no oversized group this time
   for (int i = 0; i < 6; i++) {
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
@@ -965,11 +1082,13 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
 
 static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
                     const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1) {
-  msm_pending pend;
   *result = hostg1::infinity();
-  int rc = msm_enqueue(ctx, b, off, stride, n, d_scalars, sc_stride, false, &pend);
-  if (rc) return rc;
-  return msm_finish(ctx, &pend, result);
+  for (;;) {
+    msm_pending pend;
+    int rc = msm_enqueue(ctx, b, off, stride, n, d_scalars, sc_stride, false, &pend);
+    if (rc) return rc;
+    if ((rc = msm_finish(ctx, &pend, result)) != MSM_RETRY) return rc;
+  }
 }
 
 static int range_check(const bn256_bases* b, size_t off, size_t n, size_t stride = 1) {
@@ -1179,6 +1298,7 @@ static int multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, con
   tmp.n = total_n;
   tmp.levels = 1;
   tmp.c = 0;
+  tmp.top_scale = 1;
   return msm_enqueue(ctx, &tmp, 0, 1, total_n, sc, 1, hold_stream, pend);
 }
 
@@ -1188,17 +1308,17 @@ extern "C" int bn256_msm_multi_strided(bn256_ctx* ctx, int k, const bn256_bases*
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !n || !scalars_be))) return BN256_EINVAL;
   SINGLE_DEVICE_ONLY(ctx);
   HIPCHK(hipSetDevice(ctx->device));
-  {
+  for (;;) {
     msm_pending pend;
     bool single;
     int rc = multi_enqueue(ctx, k, b, off, stride, n, scalars_be, false, &pend, &single);
     if (rc) return rc;
-    if (single) {
-      hostg1::Pt r;
-      if ((rc = msm_finish(ctx, &pend, &r))) return rc;
-      hostg1::marshal(out_xy_be, r);
-      return BN256_OK;
-    }
+    if (!single) break;
+    hostg1::Pt r;
+    if ((rc = msm_finish(ctx, &pend, &r)) == MSM_RETRY) continue;
+    if (rc) return rc;
+    hostg1::marshal(out_xy_be, r);
+    return BN256_OK;
   }
   hostg1::Pt total = hostg1::infinity();
   float ms[7] = {0};
@@ -2070,6 +2190,7 @@ static int fr_multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, 
   tmp.n = total;
   tmp.levels = 1;
   tmp.c = 0;
+  tmp.top_scale = 1;
   return msm_enqueue(ctx, &tmp, 0, 1, total, sc, 1, hold_stream, pend);
 }
 
@@ -2080,13 +2201,16 @@ extern "C" int bn256_msm_fr_multi(bn256_ctx* ctx, int k, const bn256_bases* cons
   if (!ctx || k < 0 || !out_xy_be || (k && (!b || !off || !stride || !n || !v || !v_off || !v_stride))) return BN256_EINVAL;
   SINGLE_DEVICE_ONLY(ctx);
   memset(out_xy_be, 0, 64);
-  msm_pending pend;
-  int rc = fr_multi_enqueue(ctx, k, b, off, stride, n, v, v_off, v_stride, scale_be, false, &pend);
-  if (rc) return rc;
-  hostg1::Pt r;
-  if ((rc = msm_finish(ctx, &pend, &r))) return rc;
-  hostg1::marshal(out_xy_be, r);
-  return BN256_OK;
+  for (;;) {
+    msm_pending pend;
+    int rc = fr_multi_enqueue(ctx, k, b, off, stride, n, v, v_off, v_stride, scale_be, false, &pend);
+    if (rc) return rc;
+    hostg1::Pt r;
+    if ((rc = msm_finish(ctx, &pend, &r)) == MSM_RETRY) continue;
+    if (rc) return rc;
+    hostg1::marshal(out_xy_be, r);
+    return BN256_OK;
+  }
 }
 
 extern "C" int bn256_msm_fr_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* const* b, const size_t* off,

@@ -213,7 +213,7 @@ __device__ __forceinline__ u32 recode_carry_into(const u32 k[8], u32 w, u32 c) {
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 nb,
                                                     u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride, u32 tile_len,
-                                                    u32 sc_stride, u32* __restrict__ hist,
+                                                    u32 sc_stride, u32 top_scale, u32* __restrict__ hist,
                                                     const u32* __restrict__ offsets, u32* __restrict__ sval) {
   extern __shared__ u32 lds[];
   const u32 tile = blockIdx.x, set = blockIdx.y, ntiles = gridDim.x;
@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
     for (u32 w = w_lo; w < w_hi; w++) {
       u32 mag, sign;
       recode_digit(k, neg, w, c, carry, mag, sign);
+      if (w == W - 1) mag *= top_scale;  // see bases_precompute: the top table level is divided by top_scale
       if (mag == 0) continue;
       if (!SCATTER) {
         atomicAdd(&lds[mag - 1], 1u);
@@ -275,6 +276,17 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
 #define SORT2_TCAP (16u * SORT2_TILE)  // record slots per tile (W <= 16 windows)
 #define SORT2_CAP 35840u     // records of one group that pass B sorts inside LDS (35 * 1024)
 
+// infinity (ZZ = 0) into a bucket slot
+__device__ __forceinline__ void xyzz_mem_set_inf(xyzz_mem* p) {
+  int4* q = reinterpret_cast<int4*>(p->c);
+  const int4 z = make_int4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = z;
+}
+// Flag word shared by the sort and accumulation kernels of one call: set when a group is larger than
+// pass B's LDS capacity while the split kernels were not enqueued (see msm_enqueue_srcs).
+#define MSM_FLAG_OVERSIZED 1u
+
 // Exclusive scan of v over the first B (<= blockDim <= 1024) threads; every thread of the block must
 // call it.  Wave-level shuffles, then the 16 wave totals through LDS: two barriers in all.
 // tmp[j] (j < B) holds the inclusive value afterwards.
@@ -301,11 +313,17 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32 B, u32* tmp) {
 // kept in the record), nb without (one bucket set per window, the window is implied by the group)
 // The window width is fixed at 16 bits (the only width with 2^15 buckets per set): with the window
 // loop unrolled every digit is a static half-word of the scalar, no dynamic word selects.
+// TL (tile-local records, the c = 20 path): the record carries the scalar's index inside its tile
+// (11 bits) instead of the pass-wide index; pass B knows the tile from the run it reads.  With
+// 4 window bits, the sign and LB = 10 low key bits that is 26 bits, where (window, 20-bit index, sign,
+// low key bits) would not fit a 32-bit record.
+template <int C, bool TL>
 __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 W, u32 sc_stride,
-                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32* __restrict__ gtotal,
+                                               u32 G, u32 LB, u32 ibits, u32 key_stride, u32 top_scale,
+                                               u32* __restrict__ gtotal,
                                                u32* __restrict__ loc, u32* __restrict__ rec) {
   extern __shared__ u32 lds[];  // cnt[G], cur[G], then per-wave histograms [16][G] aliased by stage[TCAP]
-  constexpr u32 c = 16;
+  constexpr u32 c = C;
   const u32 tile = blockIdx.x, wave = threadIdx.x >> 6;
   u32* cnt = lds;
   u32* cur = lds + G;
@@ -331,13 +349,14 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
     for (u32 w = 0; w < 16; w++) {
       gg[sidx][w] = 0xffffffffu;
       rr[sidx][w] = 0;
-      if (i < hi && w < W) {
+      if (w < 255 / C + 1 && i < hi && w < W) {
         u32 mag, sign;
         recode_digit(k, neg, w, c, carry, mag, sign);
+        if (w == W - 1) mag *= top_scale;
         if (mag != 0) {
           u32 key = w * key_stride + mag - 1, grp = key >> LB;
-          u32 wfield = key_stride ? 0u : (w << ibits);
-          rr[sidx][w] = ((((wfield | (i - 0u)) << 1) | sign) << LB) | (key & lmask);
+          u32 wfield = key_stride ? 0u : (w << (TL ? 11u : ibits));
+          rr[sidx][w] = ((((wfield | (TL ? i - lo : i)) << 1) | sign) << LB) | (key & lmask);
           gg[sidx][w] = grp;
           atomicAdd(&hist[wave * G + grp], 1u);
         }
@@ -364,7 +383,7 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
   for (u32 sidx = 0; sidx < SORT2_TILE / 1024; sidx++) {
 #pragma unroll
     for (u32 w = 0; w < 16; w++) {
-      if (gg[sidx][w] != 0xffffffffu) {
+      if (w < 255 / C + 1 && gg[sidx][w] != 0xffffffffu) {
         u32 pos = atomicAdd(&cur[gg[sidx][w]], 1u);
         stage[pos] = rr[sidx][w];
       }
@@ -381,7 +400,9 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
 __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec, const u32* __restrict__ loc,
                                                      const u32* __restrict__ gtotal, u32 ntiles, u32 nbt, u32 LB, u32 NH,
                                                      u32 ibits, u32 base_off, u32 pt_stride, u32 level_stride,
-                                                     u32* __restrict__ offsets, u32* __restrict__ sval) {
+                                                     u32* __restrict__ offsets, u32* __restrict__ sval,
+                                                     xyzz_mem* __restrict__ buckets, u32 init_inf,
+                                                     u32* __restrict__ flags) {
   extern __shared__ u32 lds[];
   __shared__ u32 sh_gs, sh_m;
   const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -400,7 +421,10 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
   if (g == G - 1 && threadIdx.x == G - 1) offsets[nbt] = pre + tot;
   __syncthreads();
   const u32 gs = sh_gs, m = sh_m;
-  if (m > SORT2_CAP) return;  // left to the split kernels below
+  if (m > SORT2_CAP) {  // left to the split kernels below
+    if (threadIdx.x == 0) flags[0] = MSM_FLAG_OVERSIZED;
+    return;
+  }
   // gather: the group's run of every tile, placed back to back in stage[]
   u32 a = 0, len = 0;
   if (threadIdx.x < ntiles) {
@@ -456,6 +480,8 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
   if (threadIdx.x < B) {
     cur[threadIdx.x] = excl;
     offsets[g * B + threadIdx.x] = gs + excl;
+    // a bucket without entries: infinity on the first pass of a call (later passes leave the sum alone)
+    if (init_inf && t == 0) xyzz_mem_set_inf(&buckets[g * B + threadIdx.x]);
   }
   __syncthreads();
   const u32 imask = (1u << ibits) - 1u;
@@ -472,14 +498,132 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
   for (u32 e = threadIdx.x; e < m; e += blockDim.x) sval[gs + e] = stage[e];
 }
 
+// Pass B for tile-local records (c = 20: 2^19 buckets, G = 512 groups of B = 1024 keys, ~26.6 k records per
+// group at 2^20 points).  Same structure as k_group_sort; a record's tile is recovered from its
+// position in the gathered runs (binary search over the run ends), so that registers hold
+// (window, tile * 2048 + local index, sign) and the low key bits as two words per record, and LDS
+// only ever holds 32-bit words: the gathered records first, the final entries after placement.
+// LDS: wcnt[NH][B], cur[B], tmp[1024], tile_a[1024], run_end[1024], stage[SORT20_CAP].
+#define SORT20_CAP 32768u
+__global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ rec, const u32* __restrict__ loc,
+                                                        const u32* __restrict__ gtotal, u32 ntiles, u32 nbt, u32 LB,
+                                                        u32 NH, u32 base_off, u32 pt_stride, u32 level_stride,
+                                                        u32* __restrict__ offsets, u32* __restrict__ sval,
+                                                        xyzz_mem* __restrict__ buckets, u32 init_inf,
+                                                        u32* __restrict__ flags) {
+  extern __shared__ u32 lds[];
+  __shared__ u32 sh_gs, sh_m;
+  const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  u32* wcnt = lds;
+  u32* cur = lds + NH * B;
+  u32* tmp = cur + B;
+  u32* tile_a = tmp + 1024;
+  u32* run_end = tile_a + 1024;
+  u32* stage = run_end + 1024;
+  u32 tot = threadIdx.x < G ? gtotal[threadIdx.x] : 0;
+  u32 pre = block_exclusive_scan(tot, G, tmp);
+  if (threadIdx.x == g) {
+    sh_gs = pre;
+    sh_m = tot;
+  }
+  if (g == G - 1 && threadIdx.x == G - 1) offsets[nbt] = pre + tot;
+  __syncthreads();
+  const u32 gs = sh_gs, m = sh_m;
+  if (m > SORT20_CAP) {  // left to the split kernels
+    if (threadIdx.x == 0) flags[0] = MSM_FLAG_OVERSIZED;
+    return;
+  }
+  u32 a = 0, len = 0;
+  if (threadIdx.x < ntiles) {
+    a = loc[(size_t)threadIdx.x * (G + 1) + g];
+    len = loc[(size_t)threadIdx.x * (G + 1) + g + 1] - a;
+    tile_a[threadIdx.x] = a;
+  }
+  (void)block_exclusive_scan(len, ntiles, tmp);  // tmp[t] = end of tile t's run afterwards
+  if (threadIdx.x < 1024) run_end[threadIdx.x] = threadIdx.x < ntiles ? tmp[threadIdx.x] : m;
+  for (u32 t0 = wave; t0 < ntiles; t0 += 16 * 8) {
+    u32 beg[8], len8[8], v[8];
+    const u32* src[8];
+#pragma unroll
+    for (u32 u = 0; u < 8; u++) {
+      const u32 t = t0 + 16 * u;
+      beg[u] = 0;
+      len8[u] = 0;
+      src[u] = rec;
+      if (t < ntiles) {
+        beg[u] = t ? tmp[t - 1] : 0;
+        len8[u] = tmp[t] - beg[u];
+        src[u] = rec + (size_t)t * SORT2_TCAP + tile_a[t];
+      }
+    }
+#pragma unroll
+    for (u32 u = 0; u < 8; u++) v[u] = lane < len8[u] ? src[u][lane] : 0u;
+#pragma unroll
+    for (u32 u = 0; u < 8; u++)
+      if (lane < len8[u]) stage[beg[u] + lane] = v[u];
+#pragma unroll
+    for (u32 u = 0; u < 8; u++)
+      for (u32 j = lane + 64; j < len8[u]; j += 64) stage[beg[u] + j] = src[u][j];
+  }
+  for (u32 j = threadIdx.x; j < NH * B; j += blockDim.x) wcnt[j] = 0;
+  __syncthreads();
+  // the thread's records move to registers: (window | tile * 2048 + local | sign) and the low key bits
+  u32 r[SORT20_CAP / 1024], kk[SORT20_CAP / 1024];
+#pragma unroll
+  for (u32 it = 0; it < SORT20_CAP / 1024; it++) {
+    const u32 e = it * 1024 + threadIdx.x;
+    r[it] = 0;
+    kk[it] = 0;
+    if (e < m) {
+      const u32 x = stage[e];
+      // tile = first t with run_end[t] > e (ntiles <= 1024: ten steps)
+      u32 lo_t = 0, hi_t = ntiles - 1;
+      while (lo_t < hi_t) {
+        const u32 mid = (lo_t + hi_t) >> 1;
+        if (run_end[mid] <= e) lo_t = mid + 1; else hi_t = mid;
+      }
+      const u32 v = x >> LB;                       // (w << 11 | local) << 1 | sign
+      const u32 local = (v >> 1) & 2047u, w = v >> 12;
+      r[it] = (((w << 20) | (lo_t * SORT2_TILE + local)) << 1) | (v & 1u);
+      kk[it] = x & (B - 1);
+    }
+  }
+  const u32 hrow = (wave & (NH - 1)) * B;
+#pragma unroll
+  for (u32 it = 0; it < SORT20_CAP / 1024; it++)
+    if (it * 1024 + threadIdx.x < m) atomicAdd(&wcnt[hrow + kk[it]], 1u);
+  __syncthreads();  // also: every stage[] word has been read, stage[] may be overwritten below
+  u32 t = 0;
+  if (threadIdx.x < B)
+    for (u32 v = 0; v < NH; v++) t += wcnt[v * B + threadIdx.x];
+  u32 excl = block_exclusive_scan(t, B, tmp);
+  if (threadIdx.x < B) {
+    cur[threadIdx.x] = excl;
+    offsets[g * B + threadIdx.x] = gs + excl;
+    if (init_inf && t == 0) xyzz_mem_set_inf(&buckets[g * B + threadIdx.x]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 it = 0; it < SORT20_CAP / 1024; it++) {
+    if (it * 1024 + threadIdx.x < m) {
+      u32 pos = atomicAdd(&cur[kk[it]], 1u);
+      u32 idx = (r[it] >> 1) & 0xfffffu, w = r[it] >> 21;
+      u32 tidx = w * level_stride + base_off + idx * pt_stride;
+      stage[pos] = (tidx << 1) | (r[it] & 1u);
+    }
+  }
+  __syncthreads();
+  for (u32 e = threadIdx.x; e < m; e += blockDim.x) sval[gs + e] = stage[e];
+}
+
 // ---- split path for oversized groups.  Block (g, sp) owns the group's runs of tiles [sp*TS, (sp+1)*TS).
 __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ loc,
-                                                     const u32* __restrict__ gtotal, u32 G, u32 TS, u32 LB,
+                                                     const u32* __restrict__ gtotal, u32 G, u32 TS, u32 LB, u32 cap,
                                                      u32* __restrict__ subhist) {
   extern __shared__ u32 lds[];  // h[4][B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S, wave = threadIdx.x >> 6;
-  if (gtotal[g] <= SORT2_CAP) return;
+  if (gtotal[g] <= cap) return;
   for (u32 j = threadIdx.x; j < 4 * B; j += blockDim.x) lds[j] = 0;
   __syncthreads();
   for (u32 t = sp * TS; t < (sp + 1) * TS; t++) {
@@ -493,12 +637,13 @@ __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec
 }
 // exclusive scan, in place, of an oversized group's B*S counters (bucket-major), offset by the group
 // start; one block of 1024 threads per group, thread b owns bucket b's S counters
-__global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ gtotal, u32 LB, u32* __restrict__ subhist,
-                                                        u32* __restrict__ offsets) {
+__global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ gtotal, u32 LB, u32 cap,
+                                                        u32* __restrict__ subhist, u32* __restrict__ offsets,
+                                                        xyzz_mem* __restrict__ buckets, u32 init_inf) {
   __shared__ u32 tmp[1024];
   __shared__ u32 sh_gs;
   const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, b = threadIdx.x;
-  if (gtotal[g] <= SORT2_CAP) return;
+  if (gtotal[g] <= cap) return;
   u32 tot = b < G ? gtotal[b] : 0;
   u32 pre = block_exclusive_scan(tot, G, tmp);
   if (b == g) sh_gs = pre;
@@ -512,6 +657,7 @@ __global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ 
   if (b < B) {
     u32 run = gs + excl;
     offsets[g * B + b] = run;
+    if (init_inf && t == 0) xyzz_mem_set_inf(&buckets[g * B + b]);
     for (u32 v = 0; v < SORT2_S; v++) {
       u32 cnt = row[v];
       row[v] = run;
@@ -522,11 +668,12 @@ __global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ 
 __global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec, const u32* __restrict__ loc,
                                                      const u32* __restrict__ gtotal, const u32* __restrict__ subscan,
                                                      u32 G, u32 TS, u32 LB, u32 ibits, u32 base_off, u32 pt_stride,
-                                                     u32 level_stride, u32* __restrict__ sval) {
+                                                     u32 level_stride, u32 cap, u32 tile_local,
+                                                     u32* __restrict__ sval) {
   extern __shared__ u32 cur[];  // [B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
-  if (gtotal[g] <= SORT2_CAP) return;
+  if (gtotal[g] <= cap) return;
   for (u32 b = threadIdx.x; b < B; b += blockDim.x) cur[b] = subscan[((size_t)g * B + b) * SORT2_S + sp];
   __syncthreads();
   const u32 imask = (1u << ibits) - 1u;
@@ -537,7 +684,10 @@ __global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec
       u32 r = src[j];
       u32 pos = atomicAdd(&cur[r & (B - 1)], 1u);
       u32 v = r >> LB, idx = v >> 1;
-      u32 tidx = (idx >> ibits) * level_stride + base_off + (idx & imask) * pt_stride;
+      // tile-local records: (window << 11 | index inside tile t)
+      u32 w = tile_local ? (idx >> 11) : (idx >> ibits);
+      u32 i = tile_local ? t * SORT2_TILE + (idx & 2047u) : (idx & imask);
+      u32 tidx = w * level_stride + base_off + i * pt_stride;
       sval[pos] = (tidx << 1) | (v & 1u);
     }
   }
@@ -578,7 +728,8 @@ __global__ void __launch_bounds__(256) k_tile_scan(u32* __restrict__ hist, u32 n
 template <bool SCATTER>
 __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W,
                                                 u32 nb, u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride,
-                                                u32 sc_stride, u32* __restrict__ counts, u32* __restrict__ rank,
+                                                u32 sc_stride, u32 top_scale, u32* __restrict__ counts,
+                                                u32* __restrict__ rank,
                                                 const u32* __restrict__ offsets, u32* __restrict__ sval) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -589,6 +740,7 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scal
   for (u32 w = 0; w < W; w++) {
     u32 mag, sign;
     recode_digit(k, neg, w, c, carry, mag, sign);
+    if (w == W - 1) mag *= top_scale;
     if (mag == 0) continue;
     u32 key = (precomp ? 0u : w * nb) + mag - 1u;
     if (!SCATTER) {
@@ -671,15 +823,26 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32
 }
 
 // ------------------------------------------------------------------ bucket accumulation
+#define FIX_CAP 32
+#define HEAVY_SPLIT_MIN 4096u  // partials above which one bucket is reduced by HEAVY_PARTS workgroups
+#define HEAVY_PARTS 64u
+#define HEAVY_SLOTS 1024u      // such buckets per pass (2T / 4096 <= 256 at the default chunk length)
 // Thread t owns the sorted entries [t*K, (t+1)*K); bucket boundaries come from offsets[].
 // Runs of one bucket are summed with mixed additions.  A run that neither continues from
 // thread t-1 nor into thread t+1 is a complete bucket; otherwise it is a partial: slot 2t if
 // it continues from the previous thread (possibly also into the next), slot 2t+1 if it only
 // continues into the next.
+// add_prev (second and later passes of one call): a run that STARTS its bucket in this thread begins
+// from the bucket's current content instead of infinity, so the passes' sums meet in one bucket array
+// with no extra addition (k_bucket_fix then leaves buckets without entries alone).
 __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ table, const u32* __restrict__ sval,
-                                                    const u32* __restrict__ offsets, u32 nbt, u32 K,
+                                                    const u32* __restrict__ offsets, u32 nbt, u32 K, u32 add_prev,
                                                     xyzz_mem* __restrict__ buckets,
-                                                    xyzz_mem* __restrict__ partials) {
+                                                    xyzz_mem* __restrict__ partials, const u32* __restrict__ flags,
+                                                    u32* __restrict__ lastb) {
+  // an oversized group that no split kernel handled left part of sval[] unwritten: do not gather through
+  // it (the host repeats the call with the split kernels, msm_finish)
+  if (flags[0] & MSM_FLAG_OVERSIZED) return;
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   u32 M = offsets[nbt];
   u64 start64 = (u64)t * K;
@@ -697,6 +860,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
   bool head = offsets[cur] < start;  // first run continues from the previous thread
   xyzz acc;
   xyzz_set_inf(acc);
+  if (add_prev && !head) xyzz_load(acc, &buckets[cur]);
   for (u32 e = start; e < end; e++) {
     u32 val = sval[e];
     if (e >= bend) {
@@ -707,6 +871,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
         bend = offsets[cur + 1];
       } while (e >= bend);
       xyzz_set_inf(acc);
+      if (add_prev) xyzz_load(acc, &buckets[cur]);
     }
     fe x2, y2;
     if (aff_load(x2, y2, &table[val >> 1], (val & 1u) != 0)) xyzz_madd(acc, x2, y2);
@@ -714,20 +879,65 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
   bool tail = bend > end;
   xyzz_mem* dst = head ? &partials[2 * (size_t)t] : (tail ? &partials[2 * (size_t)t + 1] : &buckets[cur]);
   xyzz_store(dst, acc);
+  if (lastb) lastb[t] = cur | (tail ? 0x80000000u : 0u);  // for k_fix_boundary
+}
+
+// The fix-up seen from the chunks instead of the buckets (dense passes: far fewer chunk boundaries than
+// buckets): quad t looks at the bucket its chunk's last run belongs to; if that bucket starts in
+// chunk t and runs on into the next chunks, this quad joins its partial sums (slot 2 t + 1, then
+// 2 t' for the chunks it covers) exactly as k_bucket_fix does.  Buckets without entries were set to
+// infinity by the sort kernels.
+__global__ void __launch_bounds__(64) k_fix_boundary(const u32* __restrict__ offsets, u32 nbt, u32 K,
+                                                     const u32* __restrict__ lastb, xyzz_mem* __restrict__ buckets,
+                                                     const xyzz_mem* __restrict__ partials,
+                                                     u32* __restrict__ heavy_count, u32* __restrict__ heavy_list,
+                                                     const u32* __restrict__ flags) {
+  if (flags[0] & MSM_FLAG_OVERSIZED) return;
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 t0 = tid >> 2, role = tid & 3u;
+  if ((u64)t0 * K >= offsets[nbt]) return;
+  u32 v = lastb[t0];
+  if (!(v >> 31)) return;             // the chunk's last run ends inside the chunk
+  u32 b = v & 0x7fffffffu;
+  u32 lo = offsets[b], hi = offsets[b + 1];
+  if ((u64)lo < (u64)t0 * K) return;  // the bucket started in an earlier chunk: that chunk's quad has it
+  u32 t1 = (hi - 1) / K;
+  if (t1 - t0 + 1 > FIX_CAP) {
+    if (role == 0) {
+      u32 ent = b;
+      if (t1 - t0 + 1 > HEAVY_SPLIT_MIN && b < (1u << 20)) {
+        u32 slot = atomicAdd(heavy_count + 1, 1u);
+        if (slot < HEAVY_SLOTS) ent = b | 0x80000000u | (slot << 20);
+      }
+      heavy_list[atomicAdd(heavy_count, 1u)] = ent;
+    }
+    return;
+  }
+  xyzz acc, p;
+  xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
+  xyzz_load(p, &partials[2 * (size_t)(t0 + 1)]);
+  for (u32 t = t0 + 1; t <= t1; t++) {
+    xyzz pn, r;
+    if (t < t1) xyzz_load(pn, &partials[2 * (size_t)(t + 1)]);
+    xyzz_add_quad(r, acc, p, role);
+    acc = r;
+    p = pn;
+  }
+  if (role == 0) xyzz_store(&buckets[b], acc);
 }
 
 // One thread per bucket: empty buckets become infinity; buckets that straddle chunks
 // t0 < t1 are the sum of partials 2*t0+1, 2*t (t0 < t < t1), 2*t1.  Buckets with more than
 // FIX_CAP partials (heavy buckets: skewed scalar distributions such as the Bulletproofs
 // 0/1 bit vectors, go/bp/main.go:84-85, or a narrow top window) are queued for k_heavy.
-#define FIX_CAP 32
-#define HEAVY_SPLIT_MIN 4096u  // partials above which one bucket is reduced by HEAVY_PARTS workgroups
-#define HEAVY_PARTS 64u
-#define HEAVY_SLOTS 1024u      // such buckets per pass (2T / 4096 <= 256 at the default chunk length)
-__global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offsets, u32 nbt, u32 K,
+__global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offsets, u32 nbt, u32 K, u32 add_prev,
                                                    xyzz_mem* __restrict__ buckets,
                                                    const xyzz_mem* __restrict__ partials,
-                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
+                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list,
+                                                   const u32* __restrict__ flags) {
+  // an oversized group that no split kernel handled left part of offsets[] unwritten: chunk numbers
+  // derived from it would index partials[] out of bounds (the host repeats the call, msm_finish)
+  if (flags[0] & MSM_FLAG_OVERSIZED) return;
   // one quad (4 lanes) per bucket: the serial chain of additions runs quad-cooperatively
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   u32 b = tid >> 2, role = tid & 3u;
@@ -735,6 +945,7 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
   u32 lo = offsets[b], hi = offsets[b + 1];
   xyzz acc;
   if (lo == hi) {
+    if (add_prev) return;  // no entry in this pass: the earlier passes' sum stays
     xyzz_set_inf(acc);
     if (role == 0) xyzz_store(&buckets[b], acc);
     return;
@@ -862,6 +1073,31 @@ __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32
   xyzz_load(b, p + half);
   xyzz_add_quad(r, a, b, role);
   if (role == 0) xyzz_store(p, r);
+}
+
+// The same level with one LANE per output element: the first levels of a 2^19-bucket reduction are
+// 2^17..2^18 independent additions each -- throughput work, not a latency chain, so the quad form
+// (4 lanes per addition, every lane executing every multiplication's instructions) is the wrong shape
+// there.  The host picks this kernel for levels of >= 2^17 additions.
+__global__ void __launch_bounds__(256) k_fold_lane(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  u32 half = (nb >> level) >> 1;
+  u32 rows = level + 1;
+  u64 per_set = (u64)rows * half;
+  const u64 total = per_set * nsets, step = (u64)gridDim.x * blockDim.x;
+  // grid-stride: the host launches a whole number of waves per SIMD (161 VGPRs: three fit) so that a level
+  // never ends in a sparsely filled extra round
+  for (u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += step) {
+    u32 set = (u32)(tid / per_set);
+    u32 rem = (u32)(tid % per_set);
+    u32 row = rem / half, i = rem % half;
+    u32 base = row == 0 ? 0u : (nb >> row);
+    xyzz_mem* p = buckets + (size_t)set * nb + base + i;
+    xyzz a, b, r;
+    xyzz_load(a, p);
+    xyzz_load(b, p + half);
+    xyzz_add(r, a, b);
+    xyzz_store(p, r);
+  }
 }
 
 // Canonical, non-Montgomery X,Y,ZZ,ZZZ (8 x u32 LE each) of T and G_k for the host tail.

@@ -94,11 +94,12 @@ int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, co
  * sums, packed results) are carved from a file-scope __device__ array of BN256_NOALLOC_SCRATCH_BYTES
  * that every GPU the library runs on holds until the process ends; its device address is resolved once
  * per device by bn256_ctx_create.  A call whose workspaces do not fit returns BN256_ESCRATCH before
- * anything is enqueued: 256 MiB hold a fixed-base (BN256_PRECOMPUTE) call of up to 2^20 points and a
- * table-less call of up to 2^18.  All contexts on one GPU share that GPU's array and it keeps the last
- * call's contents (the pipeline initialises what it reads): calls that overlap on one GPU -- two
- * contexts, two threads -- race; serialise them.  The other entry points are unaffected. */
-#define BN256_NOALLOC_SCRATCH_BYTES ((size_t)256 << 20)
+ * anything is enqueued: the 384 MiB hold a fixed-base (BN256_PRECOMPUTE) call of up to 2^20 points
+ * (342 MiB with the split-sort workspace that skewed scalars need) and a table-less call of up to
+ * 2^20.  All contexts on one GPU share that GPU's array and it keeps the last call's contents (the
+ * pipeline initialises what it reads): calls that overlap on one GPU -- two contexts, two threads --
+ * race; serialise them.  The other entry points are unaffected. */
+#define BN256_NOALLOC_SCRATCH_BYTES ((size_t)384 << 20)
 int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                           uint8_t out_xy_be[64]);
 

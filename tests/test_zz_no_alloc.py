@@ -36,6 +36,13 @@ def test_noalloc_matches_msm_dev_twice_second_smaller(eng, orc):
         # the allocating entry points are unaffected by the swap of workspaces
         assert eng.msm_dev(h, v.device_ptr(), n) == want
         assert eng.msm_dev_noalloc(h, v.device_ptr(), 0) == bytes(64)
+        # skewed scalars (every entry in one bucket): the call is repeated with the split-sort kernels,
+        # whose workspace comes out of the same array
+        ones = eng.fr_upload((1).to_bytes(32, "big") * n)
+        got3, want3 = _pair(eng, h, ones, n)
+        assert got3 == want3 == orc.synth_msm_closed_form_scalars(SEED_B, (1).to_bytes(32, "big") * n)
+        ones.free()
+        assert eng.msm_dev_noalloc(h, v.device_ptr(), n) == want
     finally:
         h.free()
         v.free()
@@ -54,7 +61,7 @@ def test_noalloc_small_and_tableless_against_oracle(eng, orc):
     finally:
         h.free()
         v.free()
-    n = 1 << 18  # the largest table-less call the array holds (16 bucket sets of 2^15)
+    n = 1 << 20  # the largest table-less call the array holds (16 bucket sets of 2^15)
     h = eng.random_bases(SEED_B, n)
     v = eng.fr_random(SEED_S, n)
     try:
@@ -68,8 +75,8 @@ def test_noalloc_small_and_tableless_against_oracle(eng, orc):
 def test_noalloc_rejects_sizes_beyond_the_array(eng):
     import crypto_amd
     from crypto_amd.engine import BN256Error
-    n = 1 << 21
-    h = eng.random_bases(SEED_B, n, flags=crypto_amd.PRECOMPUTE)
+    n = 1 << 21   # table-less: 2^25 sort records, 400 MiB of workspaces
+    h = eng.random_bases(SEED_B, n)
     v = eng.fr_random(SEED_S, n)
     try:
         with pytest.raises(BN256Error) as ei:
