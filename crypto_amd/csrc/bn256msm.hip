@@ -156,6 +156,7 @@ struct bn256_bases {
   size_t n;       // points per level
   int levels;     // 1, or W when precomputed
   int c;          // window bits the levels were built for (0 when levels == 1)
+  bool no_inf;    // proven to hold no point at infinity (k_accumulate skips the test)
   u32 top_scale;  // the top level holds (1 / top_scale) * 2^(c (W-1)) * P and its digits are multiplied by top_scale
   size_t cap;     // bytes of the block behind d (pool)
   int dev;
@@ -441,6 +442,7 @@ static bn256_bases* bases_alloc(size_t n, int levels, int c, int* rc) {
   b->levels = levels;
   b->c = c;
   b->top_scale = 1;
+  b->no_inf = false;
   b->d = nullptr;
   size_t bytes = std::max<size_t>(1, n) * (size_t)levels * sizeof(aff_mem);
   hipError_t e = pool::alloc((void**)&b->d, bytes, &b->cap, &b->dev);
@@ -563,10 +565,11 @@ extern "C" int bn256_bases_upload(bn256_ctx* ctx, const uint8_t* xy_be, size_t n
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, b); return BN256_EHIP; }
     u32 err = ctx->h_err[0];
-    if (err) {
+    if (err & 3u) {
       bn256_bases_free(ctx, b);
       return (err & 1u) ? BN256_ECOORD : BN256_ENOTONCURVE;
     }
+    b->no_inf = !(err & 4u);  // multiples 2^(c w) P of a point of prime order are not infinity either
     if (precomp) {
       rc = bases_precompute(ctx, b);
       if (rc == BN256_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BN256_EHIP;
@@ -991,8 +994,12 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     // empty buckets were initialised by the two-pass sort), by buckets otherwise
     const bool by_chunks = two && nbt > T;
     u32* lastb = by_chunks ? (u32*)ctx->ws[WS_LASTB] : (u32*)nullptr;
-    hipLaunchKernelGGL(k_accumulate, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                       (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
+    if (b->no_inf)
+      hipLaunchKernelGGL(k_accumulate<true>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
+                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
+    else
+      hipLaunchKernelGGL(k_accumulate<false>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
+                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
     HIPCHK(hipEventRecord(ctx->ev[4], s));
     if (by_chunks)
       hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(T * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K,
@@ -1299,6 +1306,7 @@ static int multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, con
   tmp.levels = 1;
   tmp.c = 0;
   tmp.top_scale = 1;
+  tmp.no_inf = false;
   return msm_enqueue(ctx, &tmp, 0, 1, total_n, sc, 1, hold_stream, pend);
 }
 
@@ -1883,6 +1891,7 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
       e = hipStreamSynchronize(ctx->stream);
     }
     if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, b); return BN256_EHIP; }
+    b->no_inf = true;  // k_i * G0 with 0 < k_i < n
     if (precomp) {
       rc = bases_precompute(ctx, b);
       if (rc == BN256_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BN256_EHIP;
@@ -2191,6 +2200,7 @@ static int fr_multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, 
   tmp.levels = 1;
   tmp.c = 0;
   tmp.top_scale = 1;
+  tmp.no_inf = false;
   return msm_enqueue(ctx, &tmp, 0, 1, total, sc, 1, hold_stream, pend);
 }
 

@@ -91,6 +91,16 @@ __device__ __forceinline__ bool aff_load(fe& x, fe& y, const aff_mem* p, bool ne
   if (neg) y = fe_neg(y);  // limbs in (-2^29, 0]: still magnitude < 2^29
   return any != 0;
 }
+// The same for a table that holds no point at infinity.
+__device__ __forceinline__ void aff_load_nz(fe& x, fe& y, const aff_mem* p, bool neg) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  u32 wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32 wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+  x = fe_unpack256(wx);
+  y = fe_unpack256(wy);
+  if (neg) y = fe_neg(y);
+}
 __device__ __forceinline__ void aff_store(aff_mem* p, const fe& x_canon, const fe& y_canon) {
   u32 wx[8], wy[8];
   fe_pack256(wx, x_canon);

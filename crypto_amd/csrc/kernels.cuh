@@ -835,6 +835,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32
 // add_prev (second and later passes of one call): a run that STARTS its bucket in this thread begins
 // from the bucket's current content instead of infinity, so the passes' sums meet in one bucket array
 // with no extra addition (k_bucket_fix then leaves buckets without entries alone).
+// NOINF: the table is known to hold no point at infinity (generated bases; uploads without a zero
+// point): the 16-instruction test per gathered base goes.
+template <bool NOINF>
 __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ table, const u32* __restrict__ sval,
                                                     const u32* __restrict__ offsets, u32 nbt, u32 K, u32 add_prev,
                                                     xyzz_mem* __restrict__ buckets,
@@ -874,7 +877,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
       if (add_prev) xyzz_load(acc, &buckets[cur]);
     }
     fe x2, y2;
-    if (aff_load(x2, y2, &table[val >> 1], (val & 1u) != 0)) xyzz_madd(acc, x2, y2);
+    if (NOINF) {
+      aff_load_nz(x2, y2, &table[val >> 1], (val & 1u) != 0);
+      xyzz_madd(acc, x2, y2);
+    } else if (aff_load(x2, y2, &table[val >> 1], (val & 1u) != 0)) {
+      xyzz_madd(acc, x2, y2);
+    }
   }
   bool tail = bend > end;
   xyzz_mem* dst = head ? &partials[2 * (size_t)t] : (tail ? &partials[2 * (size_t)t + 1] : &buckets[cur]);
@@ -1078,7 +1086,9 @@ __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32
 // The same level with one LANE per output element: the first levels of a 2^19-bucket reduction are
 // 2^17..2^18 independent additions each -- throughput work, not a latency chain, so the quad form
 // (4 lanes per addition, every lane executing every multiplication's instructions) is the wrong shape
-// there.  The host picks this kernel for levels of >= 2^17 additions.
+// there.  The host picks this kernel for levels of >= 2^17 additions.  It is issue-bound like the
+// accumulation (~3300 instructions per general addition; moving the 144-byte records through LDS with
+// coalesced 16-byte accesses instead of nine strided loads per lane changed nothing: measured).
 __global__ void __launch_bounds__(256) k_fold_lane(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
   u32 half = (nb >> level) >> 1;
   u32 rows = level + 1;
@@ -1136,7 +1146,7 @@ __global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict_
 }
 
 // ------------------------------------------------------------------ Marshal / Unmarshal
-// err bits: 1 coordinate >= p, 2 not on curve
+// err bits: 1 coordinate >= p, 2 not on curve; 4 (no error) some point is the point at infinity
 __global__ void __launch_bounds__(256) k_points_from_be(const uint8_t* __restrict__ in, aff_mem* __restrict__ out,
                                                         u32 n, u32* __restrict__ err) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1149,6 +1159,7 @@ __global__ void __launch_bounds__(256) k_points_from_be(const uint8_t* __restric
   for (int j = 0; j < 8; j++) any |= wx[j] | wy[j];
   if (any == 0) {
     aff_store_inf(&out[i]);
+    atomicOr(err, 4u);  // not an error: the handle holds a point at infinity (k_accumulate then tests for it)
     return;
   }
   if (u256_geq_p(wx) || u256_geq_p(wy)) {
