@@ -206,7 +206,8 @@ def worker(args) -> int:
             if n == (1 << 20) and not args.no_precompute and not args.window_bits:
                 pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_2p20.json")))[-1]
                 with open(pmc_file) as f:
-                    pmc = json.load(f)["k_accumulate"]
+                    pmc = json.load(f)
+                    pmc = pmc.get("k_accumulate<true>") or pmc["k_accumulate"]
                 traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
                 # executed work next to the canonical 23 120 IMAD/point ("report executed
                 # IMADs so waste is visible"): VALU lane-operations of all kinds per point
