@@ -104,6 +104,25 @@ def test_skewed_scalars_take_the_split_path_and_recover(wide, orc, table):
     _check(wide, orc, h, uniform)
 
 
+def test_repeated_scalars_chains_and_heavy_queue(wide, orc, table):
+    """k_fix_boundary joins up to FIX_CAP (32) partial sums of a bucket as one quad's serial chain; buckets
+    that span more chunks go to the heavy queue (k_heavy).  Scalars drawn from d distinct values put
+    13 n / (13 d) entries into each of <= 13 d buckets: 1-2, ~11, ~55 and ~440 chunks of 16 entries."""
+    import numpy as np
+    h, n = table
+    rng = np.random.default_rng(21)
+    for d in (40000, 1500, 300, 37):
+        pool = [int.from_bytes(rng.bytes(32), "big") % N for _ in range(d)]
+        pick = rng.integers(0, d, size=n)
+        _check(wide, orc, h, _be(pool[i] for i in pick))
+    # chained, heavy and ordinary buckets in one call
+    pool = [int.from_bytes(rng.bytes(32), "big") % N for _ in range(1500)]
+    s = bytearray(orc.synth_scalars(0xC28, n))
+    for i in range(0, n // 2):
+        s[32 * i:32 * i + 32] = pool[(i * 7) % (1500 if i % 3 else 20)].to_bytes(32, "big")
+    _check(wide, orc, h, bytes(s))
+
+
 def test_passes_share_one_bucket_array(orc, monkeypatch):
     """A call of several passes: later passes start every bucket from its current sum (k_accumulate's
     add_prev) and leave buckets without entries alone.  Passes of 2^18 points; the third pass alone is
