@@ -2,4 +2,4 @@
 olegfomenko/crypto's go/bp and go/bppp provers.  The compute path is the HIP library
 libbn256msm.so (crypto_amd/csrc, C ABI in include/bn256msm.h); this package is the thin
 Python host side used by tests and bench.py."""
-from .engine import BN256Error, Bases, Engine, FrVec, PRECOMPUTE  # noqa: F401
+from .engine import ASYNC_LANES, BN256Error, Bases, Engine, FrVec, PRECOMPUTE  # noqa: F401

@@ -170,7 +170,6 @@ struct bn256_bases {
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
        WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_COUNT };
 
-#define BN256_ASYNC_LANES 3
 struct bn256_ctx {
   int device;
   hipStream_t stream;

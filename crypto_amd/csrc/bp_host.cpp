@@ -983,7 +983,16 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
       fprintf(stderr, "[wnla] rounds=%zu ms: dot=%.2f msm=%.2f host_point=%.2f point_fold=%.2f fr_fold=%.2f other=%.2f\n",
               res.X.size(), pf.t[PF_DOT], pf.t[PF_MSM], pf.t[PF_HOSTPT], pf.t[PF_PTFOLD], pf.t[PF_FRFOLD], pf.t[PF_OTHER]);
   };
+  const bool per_round = getenv("BP_PROFILE") && atoi(getenv("BP_PROFILE")) >= 2;
+  double prev[6] = {0, 0, 0, 0, 0, 0};
   for (;;) {
+    if (per_round) {  // BP_PROFILE=2: the split of every round
+      if (!res.X.empty())
+        fprintf(stderr, "[wnla] round %zu |l|=%zu: dot=%.3f msm=%.3f host_point=%.3f point_fold=%.3f fr_fold=%.3f other=%.3f\n",
+                res.X.size(), 2 * l.n, pf.t[0] - prev[0], pf.t[1] - prev[1], pf.t[2] - prev[2], pf.t[3] - prev[3],
+                pf.t[4] - prev[4], pf.t[5] - prev[5]);
+      for (int i = 0; i < 6; i++) prev[i] = pf.t[i];
+    }
     Fr roinv = fr_inv(ro);
     lap(PF_OTHER);
     if (l.n + n.n < 6) {
@@ -1001,8 +1010,24 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     View c0 = evens(c.n), c1 = odds(c.n), l0 = evens(l.n), l1 = odds(l.n), n0 = evens(n.n), n1 = odds(n.n);
     View G0 = evens(G.n), G1 = odds(G.n), H0 = evens(H.n), H1 = odds(H.n);
     Fr mu2 = mul(mu, mu);
-    // the two commitments' MSMs go to two lanes of the library; the round's inner products run on
-    // the context's own stream meanwhile (none of the three needs another's result)
+    // H_ = H0 (+) y*H1 ; G_ = ro*G0 (+) y*G1   (docs_test.go:1325-1326), ragged folds on device.  Neither
+    // needs anything of this round but y and ro, and y comes from the reader before X and R exist
+    // (docs_test.go:1294), so both folds -- ~0.5 ms latency chains of ~130 doublings whatever the length --
+    // go to two lanes FIRST and run under the whole round instead of after it (9 of the 28 ms at
+    // |l| = 2^20 were these chains, waited for at the end of every round).
+    uint8_t oneb[32], yb[32], rob[32];
+    fr_to_be(oneb, kFrOne);
+    fr_to_be(yb, y);
+    fr_to_be(rob, ro);
+    bn256_bases *hn = nullptr, *gn = nullptr;
+    int tg = -1, th = -1;
+    chk(bn256_fold2_submit(ctx, G.h, G0.off, G0.len, G.h, G1.off, G1.len, 2, rob, yb, &gn, &tg));
+    DevPoints Gn(ctx, gn);
+    chk(bn256_fold2_submit(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn, &th));
+    DevPoints Hn(ctx, hn);
+    lap(PF_PTFOLD);
+    // the two commitments' MSMs go to the other two lanes; the round's inner products run on the
+    // context's own stream meanwhile (none of the three needs another's result)
     int tx = devMsmFusedSubmit(ctx, {{&H, H0, &l, l1, nullptr}, {&H, H1, &l, l0, nullptr}, {&G, G0, &n, n1, &ro},
                                      {&G, G1, &n, n0, &roinv}});
     int tr = devMsmFusedSubmit(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
@@ -1024,20 +1049,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     lap(PF_HOSTPT);
     res.X.push_back(X);
     res.R.push_back(R);
-    // H_ = H0 (+) y*H1 ; G_ = ro*G0 (+) y*G1   (docs_test.go:1325-1326), ragged folds on device
-    uint8_t oneb[32], yb[32], rob[32];
-    fr_to_be(oneb, kFrOne);
-    fr_to_be(yb, y);
-    fr_to_be(rob, ro);
-    // both generator folds go to lanes (G's is a full-length chain: ro is a 256-bit scalar); the three
-    // scalar-vector folds (one call) and the host's C' run meanwhile
-    bn256_bases *hn = nullptr, *gn = nullptr;
-    int tg = -1, th = -1;
-    chk(bn256_fold2_submit(ctx, G.h, G0.off, G0.len, G.h, G1.off, G1.len, 2, rob, yb, &gn, &tg));
-    DevPoints Gn(ctx, gn);
-    chk(bn256_fold2_submit(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn, &th));
-    DevPoints Hn(ctx, hn);
-    lap(PF_PTFOLD);
+    // the three scalar-vector folds (one call) and the host's C' run while the generator folds finish
     DevFr c_, l_, n_;
     devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
     lap(PF_FRFOLD);

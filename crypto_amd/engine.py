@@ -11,6 +11,7 @@ from typing import Iterable, Sequence
 from . import _lib
 
 PRECOMPUTE = 1
+ASYNC_LANES = 4  # BN256_ASYNC_LANES (include/bn256msm.h): calls in flight per context
 INF = bytes(64)
 
 

@@ -107,14 +107,16 @@ int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size
  * (go/bp/main.go:89,95), L and R of an inner-product level (go/bp/main.go:340-341), the WNLA
  * round's X and R (go/bppp/docs_test.go:1312-1320) -- none of which needs another's result.  The reference computes
  * them one after the other on its single goroutine; here submit hands the whole call (enqueueing the
- * pipeline, waiting for it, the host tail) to one of 3 internal lanes -- each a context of its own
+ * pipeline, waiting for it, the host tail) to one of BN256_ASYNC_LANES internal lanes -- each a context of its own
  * (stream, workspaces) with a host thread of its own -- and returns at once; wait blocks until that
  * lane has finished and returns the same bytes bn256_msm_dev would.  The calls of the lanes overlap
  * on the GPU (+9 % points/s at 2^20 points) and their host work runs beside the caller's.  Argument
  * errors are reported by submit; errors of the call itself (BN256_ENOMEM, BN256_EHIP) by wait.  The
- * scalars must stay untouched, and the bases handle alive, until the matching wait; a fourth submit
- * without a wait returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One caller thread
- * per context, as everywhere in this library. */
+ * scalars must stay untouched, and the bases handle alive, until the matching wait; a submit while
+ * every lane holds a call returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One caller
+ * thread per context, as everywhere in this library.  Four lanes: a WNLA round has its two commitments
+ * and its two generator folds (go/bppp/docs_test.go:1312-1326) in flight together. */
+#define BN256_ASYNC_LANES 4
 int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                      int* ticket);
 int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]);
@@ -183,7 +185,7 @@ int bn256_fold_wait(bn256_ctx* ctx, int ticket);
 /* Waits for everything this context has enqueued and voids every outstanding ticket (submitted MSMs
  * and folds; a handle returned by bn256_fold2_submit keeps its memory and is freed as usual).  For a
  * caller that lost a ticket on an error path -- an exception between submit and wait -- and must not
- * leave its lane busy: without this, three such losses make every submit return BN256_EBUSY. */
+ * leave its lane busy: without this, BN256_ASYNC_LANES such losses make every submit return BN256_EBUSY. */
 int bn256_ctx_drain(bn256_ctx* ctx);
 
 /* Marshal() of n points of a handle into host memory. */

@@ -8,6 +8,8 @@ import sys
 
 import pytest
 
+import crypto_amd
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,7 +57,7 @@ def test_drain_voids_lost_tickets(eng, orc):
     v = eng.fr_random(0xD2, n)
     want = orc.synth_msm_closed_form(0xD1, 0xD2, n)
     try:
-        for _ in range(3):                       # a caller that loses its tickets
+        for _ in range(crypto_amd.ASYNC_LANES):  # a caller that loses its tickets
             eng.msm_submit(h, v.device_ptr(), n)
         with pytest.raises(BN256Error) as ei:
             eng.msm_submit(h, v.device_ptr(), n)
@@ -63,8 +65,8 @@ def test_drain_voids_lost_tickets(eng, orc):
         eng.drain()
         with pytest.raises(BN256Error):
             eng.msm_wait(0)                      # the ticket is void
-        t = [eng.msm_submit(h, v.device_ptr(), n) for _ in range(3)]
-        assert [eng.msm_wait(x) for x in t] == [want] * 3
+        t = [eng.msm_submit(h, v.device_ptr(), n) for _ in range(crypto_amd.ASYNC_LANES)]
+        assert [eng.msm_wait(x) for x in t] == [want] * crypto_amd.ASYNC_LANES
         # a lost fold ticket: the handle stays valid and its contents are complete after the drain
         f, tk = eng.fold2_submit(h, 0, 16, h, 16, 16, 3, 5)
         eng.drain()

@@ -5,6 +5,8 @@ import random
 
 import pytest
 
+import crypto_amd
+
 import bn256_ref as ref
 
 pytestmark = pytest.mark.gpu
@@ -188,10 +190,12 @@ def test_fused_multi_segment_msm(eng, orc):
     want_r = eng.msm_fr_multi(rsegs)
     tx, tr, te = eng.msm_fr_multi_submit(segs), eng.msm_fr_multi_submit(rsegs), eng.msm_fr_multi_submit([])
     assert len({tx, tr, te}) == 3
+    spare = [eng.msm_fr_multi_submit([]) for _ in range(crypto_amd.ASYNC_LANES - 3)]
     with pytest.raises(Exception):
         eng.msm_fr_multi_submit(rsegs)  # BN256_EBUSY: every lane holds a call
     assert eng.fr_dot(l, 0, 1, nh, l, 0, 1, nh) == sum(x * x for x in lv) % N
     assert eng.msm_wait(tr) == want_r and eng.msm_wait(tx) == exp and eng.msm_wait(te) == bytes(64)
+    assert all(eng.msm_wait(t) == bytes(64) for t in spare)
     # larger, table-less two-pass sizes through a lane
     big = 1 << 15
     Hb, lb = eng.random_bases(0xB1, big), eng.fr_random(0xB2, big)

@@ -153,9 +153,11 @@ def test_msm_multi_submit_matches_blocking(eng, orc):
     want = [eng.msm_multi(sg) for sg in shapes]
     assert want[2] == orc.msm(braw, sraw)
     tickets = [eng.msm_multi_submit(sg) for sg in shapes]
+    spare = [eng.msm_multi_submit([]) for _ in range(crypto_amd.ASYNC_LANES - 3)]
     with pytest.raises(Exception):
         eng.msm_multi_submit(shapes[0])  # BN256_EBUSY
     assert [eng.msm_wait(t) for t in reversed(tickets)] == list(reversed(want))
+    assert all(eng.msm_wait(t) == bytes(64) for t in spare)
     # one segment; no segment; several segments over fixed-base tables of >= 2^15 points
     t1, t0 = eng.msm_multi_submit([(G, 3, a[:17])]), eng.msm_multi_submit([])
     assert eng.msm_wait(t1) == eng.msm_multi([(G, 3, a[:17])]) and eng.msm_wait(t0) == INF
@@ -252,8 +254,10 @@ def test_fold_submit_wait(eng, orc):
     hh, th = eng.fold2_submit(g, 0, n, g, n, n, x, xinv)
     hr, tr = eng.fold2_submit(g, 0, 5, g, 7, 3, x, xinv, stride=2)
     assert len({tg, th, tr}) == 3
+    spare = [eng.msm_multi_submit([]) for _ in range(crypto_amd.ASYNC_LANES - 3)]
     with pytest.raises(Exception):
         eng.fold2_submit(g, 0, n, g, n, n, x, xinv)  # BN256_EBUSY
+    assert all(eng.msm_wait(t) == bytes(64) for t in spare)
     with pytest.raises(Exception):
         eng.msm_wait(tg)  # a fold ticket
     assert eng.fold(g, 0, g, n, n, 3, 5).download()[0] == orc.add(orc.mul(g.download(0, 1)[0], 3),
@@ -516,9 +520,11 @@ def test_submit_wait_matches_blocking_calls(eng, orc):
         tb = eng.msm_submit(h, b.data_ptr(), n)
         tc = eng.msm_submit(h, a.data_ptr(), n)
         assert len({ta, tb, tc}) == 3
-        with pytest.raises(BN256Error) as ei:  # all three lanes taken
+        spare = [eng.msm_submit(h, a.data_ptr(), 0) for _ in range(crypto_amd.ASYNC_LANES - 3)]
+        with pytest.raises(BN256Error) as ei:  # every lane taken
             eng.msm_submit(h, a.data_ptr(), n)
         assert ei.value.code == -8
+        assert all(eng.msm_wait(t) == bytes(64) for t in spare)
         assert eng.msm_wait(tb) == want_b  # any order
         assert eng.msm_wait(tc) == want_a
         assert eng.msm_wait(ta) == want_a
