@@ -2094,24 +2094,39 @@ extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* cons
   if ((rc = ws_reserve(ctx, WS_TMP, need))) return rc;
   uint8_t* d_out = (uint8_t*)ctx->ws[WS_TMP];              // k results, then every product's partial sums
   uint8_t* cur = d_out + (((size_t)k * 32 + 255) & ~(size_t)255);
-  HIPCHK(hipMemsetAsync(d_out, 0, (size_t)k * 32, ctx->stream));
-  for (int i = 0; i < k; i++) {
-    const size_t n = std::min(n_a[i], n_b[i]);
-    if (!n) continue;
-    const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
-    const u32 nthreads = (u32)((n + per - 1) / per);
-    const u32 nblk = nblocks(nthreads, 256);
-    fr* partials = (fr*)cur;
-    cur += ((size_t)nblk * sizeof(fr) + 255) & ~(size_t)255;
-    const uint8_t* mb = mu_be ? mu_be[i] : nullptr;
-    fr_arg mu;
-    memset(&mu, 0, sizeof mu);
-    if (mb) mu = fr_arg_canon(fr_arg_from_be(mb));
-    hipLaunchKernelGGL(k_fr_dot, dim3(nblk), dim3(256), 0, ctx->stream, (const uint8_t*)(a[i]->d + a_off[i] * 32),
-                       (u32)a_stride[i], (u32)n_a[i], (const uint8_t*)(b[i]->d + b_off[i] * 32), (u32)b_stride[i],
-                       (u32)n_b[i], (u32)n, per, mu, (u32)(mb != nullptr), partials);
-    hipLaunchKernelGGL(k_fr_sum, dim3(1), dim3(256), 0, ctx->stream, (const fr*)partials, nblk, d_out + 32 * i);
+  // products in launches of FR_DOT_BATCH; an empty product (nblk = 0) sums to zero
+  for (int i0 = 0; i0 < k; i0 += FR_DOT_BATCH) {
+    const int kb = std::min(k - i0, (int)FR_DOT_BATCH);
+    fr_dot_batch batch;
+    memset(&batch, 0, sizeof batch);
+    u32 max_blk = 0;
+    for (int j = 0; j < kb; j++) {
+      const int i = i0 + j;
+      const size_t n = std::min(n_a[i], n_b[i]);
+      if (!n) continue;
+      const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+      const u32 nthreads = (u32)((n + per - 1) / per);
+      fr_dot_desc& D = batch.d[j];
+      D.nblk = nblocks(nthreads, 256);
+      D.partials = (fr*)cur;
+      cur += ((size_t)D.nblk * sizeof(fr) + 255) & ~(size_t)255;
+      D.a = (const uint8_t*)(a[i]->d + a_off[i] * 32);
+      D.b = (const uint8_t*)(b[i]->d + b_off[i] * 32);
+      D.a_stride = (u32)a_stride[i];
+      D.n_a = (u32)n_a[i];
+      D.b_stride = (u32)b_stride[i];
+      D.n_b = (u32)n_b[i];
+      D.n = (u32)n;
+      D.per = per;
+      const uint8_t* mb = mu_be ? mu_be[i] : nullptr;
+      D.weighted = mb != nullptr;
+      if (mb) D.mu = fr_arg_canon(fr_arg_from_be(mb));
+      max_blk = std::max(max_blk, D.nblk);
+    }
+    if (max_blk) hipLaunchKernelGGL(k_fr_dot, dim3(max_blk, kb), dim3(256), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(k_fr_sum, dim3(kb), dim3(256), 0, ctx->stream, batch, d_out + 32 * (size_t)i0);
   }
+  HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_be, d_out, (size_t)k * 32, hipMemcpyDeviceToHost, ctx->stream));  // one copy,
   HIPCHK(hipStreamSynchronize(ctx->stream));                                                   // one wait
   return BN256_OK;

@@ -11,9 +11,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <errno.h>
@@ -959,6 +965,66 @@ Point devMsmWait(bn256_ctx* ctx, int ticket) {
   return out;
 }
 
+// One host thread that runs small jobs in order, beside the caller: wnla's running commitment
+// C' = C + y X + (y^2 - 1) R (two host scalar multiplications per round, ~85 us) is needed only by the
+// final check, so it does not have to sit between a round's last wait and the next round's submits.
+class HostChain {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  std::exception_ptr err;
+  bool busy = false, quit = false;
+  void run() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return quit || !q.empty(); });
+      if (q.empty()) return;
+      std::function<void()> job = std::move(q.front());
+      q.pop_front();
+      busy = true;
+      lk.unlock();
+      try {
+        job();
+      } catch (...) {
+        lk.lock();
+        if (!err) err = std::current_exception();
+        lk.unlock();
+      }
+      lk.lock();
+      busy = false;
+      cv.notify_all();
+    }
+  }
+
+ public:
+  HostChain() : th([this] { run(); }) {}
+  ~HostChain() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+  void push(std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      q.push_back(std::move(job));
+    }
+    cv.notify_all();
+  }
+  void wait() {  // every job pushed so far has run; rethrows the first exception of one
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return q.empty() && !busy; });
+    if (err) {
+      std::exception_ptr e = err;
+      err = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+};
+
 struct WnlaResult {
   std::vector<Point> X, R;
   FrVec l, n;
@@ -971,6 +1037,7 @@ struct WnlaResult {
 WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr c, Point C, Fr ro, Fr mu, DevFr l,
                 DevFr n, ByteStream* rd) {
   WnlaResult res;
+  HostChain chain;  // updates C beside the rounds (declared after nothing it uses: it only touches C)
   Prof pf;
   double tp = Prof::now();
   auto lap = [&](int k) {
@@ -1001,6 +1068,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
                                                                  {&G, whole(G.n), &n, whole(n.n), nullptr}}));
       res.l = l.download();
       res.n = n.download();
+      chain.wait();
       res.verified = pointEq(Cc, C);
       lap(PF_OTHER);
       report();
@@ -1053,8 +1121,10 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     DevFr c_, l_, n_;
     devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
     lap(PF_FRFOLD);
-    Point C_ = pointAdd(C, scalarMult(X, y));
-    C_ = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
+    chain.push([&C, X, R, y] {  // C is read again only after chain.wait()
+      Point C_ = pointAdd(C, scalarMult(X, y));
+      C = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
+    });
     lap(PF_HOSTPT);
     chk(bn256_fold_wait(ctx, tg));
     chk(bn256_fold_wait(ctx, th));
@@ -1062,7 +1132,6 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     G = std::move(Gn);
     H = std::move(Hn);
     c = std::move(c_);
-    C = C_;
     ro = mu;
     mu = mu2;
     l = std::move(l_);

@@ -151,19 +151,35 @@ __global__ void __launch_bounds__(256) k_fr_fold(const uint8_t* __restrict__ a, 
 // partials[block] = sum_i a_i * b_i * (weighted ? mu^(i+1) : 1) over the block's share of
 // [0, n): vectorMul (go/bp/util.go:132-142, go/bppp/util.go:143-157) and weightVectorMul
 // (go/bppp/util.go:159-176).  Thread t owns `per` consecutive indices.
-__global__ void __launch_bounds__(256) k_fr_dot(const uint8_t* __restrict__ a, u32 a_stride, u32 n_a,
-                                                const uint8_t* __restrict__ b, u32 b_stride, u32 n_b, u32 n, u32 per,
-                                                fr_arg mu_arg, u32 weighted, fr* __restrict__ partials) {
+// Up to FR_DOT_BATCH inner products per launch (blockIdx.y picks the product): a WNLA round has five
+// (go/bppp/docs_test.go:1297-1311), and in its small rounds a launch costs more than the arithmetic.
+#define FR_DOT_BATCH 8
+struct fr_dot_desc {
+  const uint8_t* a;
+  const uint8_t* b;
+  fr* partials;  // one per workgroup
+  u32 a_stride, n_a, b_stride, n_b, n, per, weighted, nblk;
+  fr_arg mu;
+};
+struct fr_dot_batch {
+  fr_dot_desc d[FR_DOT_BATCH];
+};
+__global__ void __launch_bounds__(256) k_fr_dot(fr_dot_batch batch) {
   __shared__ fr lds[256];
+  const fr_dot_desc& D = batch.d[blockIdx.y];
+  if (blockIdx.x >= D.nblk) return;  // uniform over the workgroup
+  const uint8_t* __restrict__ a = D.a;
+  const uint8_t* __restrict__ b = D.b;
+  const u32 n = D.n, per = D.per, weighted = D.weighted, a_stride = D.a_stride, b_stride = D.b_stride;
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   u64 lo64 = (u64)t * per;
   fr acc = fr_zero();
   if (lo64 < n) {
     u32 lo = (u32)lo64;
     u32 hi = (n - lo > per) ? lo + per : n;
-    u32 lim = n_a < n_b ? n_a : n_b;  // beyond the shorter vector the padded product is 0
+    u32 lim = D.n_a < D.n_b ? D.n_a : D.n_b;  // beyond the shorter vector the padded product is 0
     if (hi > lim) hi = lim;
-    fr mu = fr_to_mont(fr_from_arg(mu_arg)), w = fr_zero();
+    fr mu = fr_to_mont(fr_from_arg(D.mu)), w = fr_zero();
     if (weighted && lo < hi) {
       // w = mu^(lo+1) in Montgomery form, left-to-right square and multiply
       u32 e = lo + 1;
@@ -190,20 +206,21 @@ __global__ void __launch_bounds__(256) k_fr_dot(const uint8_t* __restrict__ a, u
     if (threadIdx.x < d) lds[threadIdx.x] = fr_add(lds[threadIdx.x], lds[threadIdx.x + d]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) partials[blockIdx.x] = lds[0];
+  if (threadIdx.x == 0) D.partials[blockIdx.x] = lds[0];
 }
-// single block: out_be = sum of partials[0..m)
-__global__ void __launch_bounds__(256) k_fr_sum(const fr* __restrict__ partials, u32 m, uint8_t* __restrict__ out_be) {
+// one workgroup per product: out_be[32 * blockIdx.x ..] = sum of its partials
+__global__ void __launch_bounds__(256) k_fr_sum(fr_dot_batch batch, uint8_t* __restrict__ out_be) {
   __shared__ fr lds[256];
+  const fr_dot_desc& D = batch.d[blockIdx.x];
   fr acc = fr_zero();
-  for (u32 i = threadIdx.x; i < m; i += 256) acc = fr_add(acc, partials[i]);
+  for (u32 i = threadIdx.x; i < D.nblk; i += 256) acc = fr_add(acc, D.partials[i]);
   lds[threadIdx.x] = acc;
   __syncthreads();
   for (u32 d = 128; d > 0; d >>= 1) {
     if (threadIdx.x < d) lds[threadIdx.x] = fr_add(lds[threadIdx.x], lds[threadIdx.x + d]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) fr_store_be(out_be, lds[0]);
+  if (threadIdx.x == 0) fr_store_be(out_be + 32 * (size_t)blockIdx.x, lds[0]);
 }
 
 // Gathers one (points view, scalars view) segment into contiguous arrays so that several
