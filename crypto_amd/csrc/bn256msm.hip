@@ -627,6 +627,7 @@ extern "C" int bn256_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t
 // What msm_finish needs to know about a pipeline that msm_enqueue put on the context's stream
 struct msm_pending {
   bool empty;   // n == 0: nothing was enqueued, the result is the identity
+  bool timed;   // phase events were recorded (see MSM_MARK)
   int c;
   u32 q, nsets;
 };
@@ -730,6 +731,25 @@ static void lane_shutdown(bn256_ctx* ctx, int l) {
 
 // One term of a sum of MSMs: a range of a bases handle (view: off, stride) and its device-resident
 // scalars (view: sc_stride).
+// segments to gather, launched GATHER_BATCH at a time (k_gather_segment, fr.cuh)
+struct gather_list {
+  hipStream_t s;
+  gather_batch batch;
+  int m = 0;
+  u32 max_n = 0;
+  explicit gather_list(hipStream_t st) : s(st) { memset(&batch, 0, sizeof batch); }
+  void add(const gather_desc& d) {
+    batch.d[m++] = d;
+    max_n = std::max(max_n, d.n);
+    if (m == GATHER_BATCH) flush();
+  }
+  void flush() {
+    if (m) hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(max_n, 256), m), dim3(256), 0, s, batch);
+    m = 0;
+    max_n = 0;
+  }
+};
+
 struct msm_src {
   const bn256_bases* b;
   size_t off, stride, n;
@@ -881,6 +901,13 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   u32* heavy_count = ctx->d_heavy;
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
+  // Phase events (bn256_last_timing) are recorded from 2^17 sorted entries on: an event between two
+  // kernels costs 6-8 us of stream time (rocprofv3 kernel trace, 64 points: kernels that follow one another
+  // directly start with no gap), seven of them a third of a small call.  BN256_PHASE_TIMING=1 forces them.
+  static const bool force_timing = getenv("BN256_PHASE_TIMING") && atoi(getenv("BN256_PHASE_TIMING")) > 0;
+  const bool timed = force_timing || nchunks > 1 || (unsigned long long)nmax * W >= (1ull << 17);
+  pend->timed = timed;
+#define MSM_MARK(i) do { if (timed) HIPCHK(hipEventRecord(ctx->ev[i], s)); } while (0)
   // The split-sort kernels (groups larger than pass B's LDS capacity: skewed scalars) are three
   // launches that do nothing for ordinary inputs.  They are enqueued only while ctx->force_split is
   // set; without them an oversized group raises MSM_FLAG_OVERSIZED, the accumulation kernels then
@@ -915,7 +942,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       ntiles = (u32)((n_ch + tile_len - 1) / tile_len);
     }
 
-    HIPCHK(hipEventRecord(ctx->ev[0], s));
+    MSM_MARK(0);
     HIPCHK(hipMemsetAsync(heavy_count, 0, (2 + HEAVY_SLOTS + 1024) * sizeof(u32), s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
@@ -937,8 +964,8 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       else
         hipLaunchKernelGGL((k_part<16, false>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W,
                            (u32)sc_stride, G2, LB2, ibits, key_stride, top_scale, gtotal, loc, rank);
-      HIPCHK(hipEventRecord(ctx->ev[1], s));
-      HIPCHK(hipEventRecord(ctx->ev[2], s));
+      MSM_MARK(1);
+      MSM_MARK(2);
       const u32 init_inf = ch == 0 ? 1u : 0u;  // buckets without entries: infinity on the call's first pass
       u32* oversized = d_flags + (split ? 1 : 0);
       if (wide)
@@ -963,18 +990,18 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
                          (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, top_scale,
                          hist, (const u32*)nullptr, (u32*)nullptr);
-      HIPCHK(hipEventRecord(ctx->ev[1], s));
+      MSM_MARK(1);
       hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
     } else {
       HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
       hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
                          (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, top_scale, counts, rank,
                          (const u32*)nullptr, (u32*)nullptr);
-      HIPCHK(hipEventRecord(ctx->ev[1], s));
+      MSM_MARK(1);
     }
     // offsets[0..nbt] = exclusive scan of counts[0..nbt] (counts[nbt] == 0) -> offsets[nbt] = total
     scan(counts, offsets, nbt + 1);
-    HIPCHK(hipEventRecord(ctx->ev[2], s));
+    MSM_MARK(2);
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
                          (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, top_scale,
@@ -985,7 +1012,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
                          (const u32*)offsets, sval);
     }
     }
-    HIPCHK(hipEventRecord(ctx->ev[3], s));
+    MSM_MARK(3);
     // 128-thread workgroups: the same single round of waves, placed and retired in finer units
     // (measured 1.051 -> 1.031 ms at 2^20; 64 threads the same, limiting residency by LDS slower)
     const u32 add_prev = ch > 0 ? 1u : 0u;  // later passes of the call add into the first pass's bucket sums
@@ -999,7 +1026,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     else
       hipLaunchKernelGGL(k_accumulate<false>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
                          (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
-    HIPCHK(hipEventRecord(ctx->ev[4], s));
+    MSM_MARK(4);
     if (by_chunks)
       hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(T * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K,
                          (const u32*)lastb, buckets, (const xyzz_mem*)partials, heavy_count, heavy_list,
@@ -1009,7 +1036,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
                          add_prev, buckets, (const xyzz_mem*)partials, heavy_count, heavy_list, (const u32*)d_flags);
     hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
                        heavy_count, (const u32*)heavy_list, (xyzz_mem*)ctx->ws[WS_HEAVYTMP]);
-    HIPCHK(hipEventRecord(ctx->ev[5], s));
+    MSM_MARK(5);
     HIPCHK(hipGetLastError());  // a failed launch is reported with its own pass, not after all of them
     if (ch + 1 < nchunks && !hold_stream) {  // per-pass phase times; the last pass is read after the reduction
       HIPCHK(hipStreamSynchronize(s));
@@ -1033,7 +1060,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   }
   hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)sum_buckets, nsets, nb, q,
                      d_pack);
-  HIPCHK(hipEventRecord(ctx->ev[6], s));
+  MSM_MARK(6);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, npack * 32 * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(ctx->h_flags, d_flags, 8, hipMemcpyDeviceToHost, s));
@@ -1042,6 +1069,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   pend->q = q;
   pend->nsets = nsets;
   return BN256_OK;
+#undef MSM_MARK
 }
 
 // Waits for the pipeline and runs the host tail; returns the sum as a host point.  MSM_RETRY (internal,
@@ -1059,7 +1087,7 @@ static int msm_finish(bn256_ctx* ctx, const msm_pending* pend, hostg1::Pt* resul
     return MSM_RETRY;
   }
   if (ctx->used_split && !ctx->h_flags[1]) ctx->force_split = 0;  // no oversized group this time
-  for (int i = 0; i < 6; i++) {
+  for (int i = 0; i < 6 && pend->timed; i++) {
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
     ctx->last_ms[i] += ms;
@@ -1292,12 +1320,15 @@ static int multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, con
   }
   if (hold_stream) HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's buffers are not ours after return
   pos = 0;
-  for (int i = 0; i < k; i++) {
-    if (!n[i]) continue;
-    hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(n[i], 256)), dim3(256), 0, ctx->stream,
-                       (const uint4*)(b[i]->d + off[i]), (u32)(stride ? stride[i] : 1), (uint4*)(pts + pos),
-                       (const uint8_t*)nullptr, 1u, none, 0u, (uint8_t*)nullptr, (u32)n[i]);
-    pos += n[i];
+  {
+    gather_list gl(ctx->stream);
+    for (int i = 0; i < k; i++) {
+      if (!n[i]) continue;
+      gl.add(gather_desc{(const uint4*)(b[i]->d + off[i]), (uint4*)(pts + pos), nullptr, nullptr,
+                         (u32)(stride ? stride[i] : 1), 1u, 0u, (u32)n[i], none});
+      pos += n[i];
+    }
+    gl.flush();
   }
   bn256_bases tmp;  // read only while enqueueing
   tmp.d = pts;
@@ -2196,17 +2227,19 @@ static int fr_multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, 
   aff_mem* pts = (aff_mem*)ctx->ws[WS_GATHER];
   uint8_t* sc = (uint8_t*)ctx->ws[WS_SCALARS];
   size_t pos = 0;
-  for (int i = 0; i < k; i++) {
-    if (!n[i]) continue;
-    const uint8_t* s_be = scale_be ? scale_be[i] : nullptr;
-    fr_arg scale;
-    memset(&scale, 0, sizeof scale);
-    if (s_be) scale = fr_arg_canon(fr_arg_from_be(s_be));
-    hipLaunchKernelGGL(k_gather_segment, dim3(nblocks(n[i], 256)), dim3(256), 0, ctx->stream,
-                       (const uint4*)(b[i]->d + off[i]), (u32)stride[i], (uint4*)(pts + pos),
-                       (const uint8_t*)(v[i]->d + v_off[i] * 32), (u32)v_stride[i], scale, (u32)(s_be != nullptr),
-                       sc + pos * 32, (u32)n[i]);
-    pos += n[i];
+  {
+    gather_list gl(ctx->stream);
+    for (int i = 0; i < k; i++) {
+      if (!n[i]) continue;
+      const uint8_t* s_be = scale_be ? scale_be[i] : nullptr;
+      fr_arg scale;
+      memset(&scale, 0, sizeof scale);
+      if (s_be) scale = fr_arg_canon(fr_arg_from_be(s_be));
+      gl.add(gather_desc{(const uint4*)(b[i]->d + off[i]), (uint4*)(pts + pos), (const uint8_t*)(v[i]->d + v_off[i] * 32),
+                         sc + pos * 32, (u32)stride[i], (u32)v_stride[i], (u32)(s_be != nullptr), (u32)n[i], scale});
+      pos += n[i];
+    }
+    gl.flush();
   }
   bn256_bases tmp;  // read only while enqueueing
   tmp.d = pts;

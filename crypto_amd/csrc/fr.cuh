@@ -227,21 +227,32 @@ __global__ void __launch_bounds__(256) k_fr_sum(fr_dot_batch batch, uint8_t* __r
 // segments become ONE MSM: dst_pts[i] = src_pts[i*pt_stride], dst_sc[i] = scale * src_sc[i*sc_stride]
 // (scale optional).  <rho * n1, G0> of the WNLA round (go/bppp/docs_test.go:1296-1306) is a
 // segment with scale = rho.
-__global__ void __launch_bounds__(256) k_gather_segment(const uint4* __restrict__ src_pts, u32 pt_stride,
-                                                        uint4* __restrict__ dst_pts, const uint8_t* __restrict__ src_sc,
-                                                        u32 sc_stride, fr_arg scale, u32 has_scale,
-                                                        uint8_t* __restrict__ dst_sc, u32 n) {
+#define GATHER_BATCH 8
+struct gather_desc {
+  const uint4* src_pts;
+  uint4* dst_pts;
+  const uint8_t* src_sc;  // null: points only, the caller supplies the scalars itself
+  uint8_t* dst_sc;
+  u32 pt_stride, sc_stride, has_scale, n;
+  fr_arg scale;
+};
+struct gather_batch {
+  gather_desc d[GATHER_BATCH];
+};
+// up to GATHER_BATCH segments per launch (blockIdx.y): the WNLA X commitment has four
+__global__ void __launch_bounds__(256) k_gather_segment(gather_batch batch) {
+  const gather_desc& D = batch.d[blockIdx.y];
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint4* sp = src_pts + (size_t)i * pt_stride * 4;
-  uint4* dp = dst_pts + (size_t)i * 4;
+  if (i >= D.n) return;
+  const uint4* sp = D.src_pts + (size_t)i * D.pt_stride * 4;
+  uint4* dp = D.dst_pts + (size_t)i * 4;
   uint4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
   dp[0] = a;
   dp[1] = b;
   dp[2] = c;
   dp[3] = d;
-  if (!src_sc) return;  // points only: the caller supplies the scalars itself
-  fr x = fr_load_be(src_sc + (size_t)i * sc_stride * 32);
-  if (has_scale) x = fr_mont(x, fr_to_mont(fr_from_arg(scale)));
-  fr_store_be(dst_sc + (size_t)i * 32, x);
+  if (!D.src_sc) return;
+  fr x = fr_load_be(D.src_sc + (size_t)i * D.sc_stride * 32);
+  if (D.has_scale) x = fr_mont(x, fr_to_mont(fr_from_arg(D.scale)));
+  fr_store_be(D.dst_sc + (size_t)i * 32, x);
 }

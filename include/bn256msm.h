@@ -271,7 +271,9 @@ int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk);
 
 /* Per-phase GPU time (ms, HIP events on the context stream) of the last bn256_msm* call:
  * [0] recode+count  [1] scan  [2] scatter  [3] bucket accumulation  [4] partial fix-up
- * [5] bucket reduction  [6] total device time.  Returns the number of values written. */
+ * [5] bucket reduction  [6] total device time.  Returns the number of values written.  Calls of fewer than
+ * 2^17 (points x windows) are not instrumented and report zeros -- the events would be a third of such a
+ * call's device time -- unless the environment has BN256_PHASE_TIMING=1. */
 int bn256_last_timing(bn256_ctx* ctx, float* ms, int cap);
 
 /* Field-arithmetic self test on the device (fe_mul inline-asm path against its portable
