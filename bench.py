@@ -216,8 +216,6 @@ def worker(args) -> int:
             traffic = executed = pmc_file = None
         phase = [p / nblk for p in phase]
         acc_s = phase[3] * 1e-3
-        # a fixed-base call above 2^21 points runs as passes of 2^21 (MSM_CHUNK in bn256msm.hip), one
-        # k_accumulate launch each; a submitted call reports the phase times of its last pass
         # a fixed-base call above one pass (2^20 points with the 20-bit windows chosen from 2^20 points on,
         # MSM chunk in bn256msm.hip) runs as consecutive passes, one k_accumulate launch each; a blocking
         # call's phase times are summed over its passes, so kernel_ms covers all n points
@@ -282,11 +280,14 @@ def worker(args) -> int:
             },
         }
         if not args.no_precompute and n >= (1 << 18) and n <= (1 << 21) and not args.window_bits:
-            # HBM rate of the sort / scatter phases (two-pass sort, 16 windows): ALGORITHMIC bytes -- 32-byte
-            # scalars in, one 4-byte record per (point, window) out, then records in, sorted entries out --
-            # over the live phase times; the PMC counters are in profiles/ and DESIGN.md 6
-            ent = 16 * n * 4
+            # HBM rate of the sort / scatter phases (two-pass sort; 13 windows of 20 bits from 2^20 points on,
+            # 16 of 16 bits below): ALGORITHMIC bytes -- 32-byte scalars in, one 4-byte record per (point,
+            # window) out, then records in, sorted entries out -- over the live phase times (summed over the
+            # passes of a call); the PMC counters are in profiles/ and DESIGN.md 6
+            windows = 13 if n >= (1 << 20) else 16
+            ent = windows * n * 4
             line["sort_hbm"] = {
+                "windows": windows,
                 "pass_a": {"bytes": 32 * n + ent, "ms": phase[0], "GB/s": (32 * n + ent) / (phase[0] * 1e-3) / 1e9},
                 "pass_b": {"bytes": 2 * ent, "ms": phase[2], "GB/s": 2 * ent / (phase[2] * 1e-3) / 1e9},
                 "peak_GB/s": 8000.0,
@@ -330,6 +331,14 @@ def worker(args) -> int:
                 entry["matches_oracle_closed_form"] = bool(orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, 1 << 24) == resb)
             line["n_2p24" if world == 1 else "strong_2p24"] = entry
         big.free()
+        # the other form of multi-GPU use: ONE context over all the devices behind the C ABI, one process
+        # (tools/multi_ctx_bench.py, a child of rank 0; the ranks wait at the barrier with their memory freed)
+        if use_dist:
+            dist.barrier()
+        if rank == 0:
+            line["multi_device_ctx"] = multi_ctx_leg(world, resb.hex())
+        if use_dist:
+            dist.barrier()
 
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -338,6 +347,23 @@ def worker(args) -> int:
         dist.destroy_process_group()
     eng.close()
     return 0
+
+
+def multi_ctx_leg(world: int, expect_hex: str) -> dict:
+    """bn256_ctx_create_multi over the node's devices, 2^24 points, in a fresh child process (a fault there
+    must not cost this run its line).  One GPU: devices 0,0 -- two shards on one device, a rehearsal."""
+    import subprocess
+    devices = ",".join(str(i) for i in range(world)) if world > 1 else "0,0"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "multi_ctx_bench.py"), "--devices", devices,
+           "--total-log2n", "24", "--expect", expect_hex]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        for ln in reversed(p.stdout.splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-300:]}
+    except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for it
+        return {"error": repr(e)[:300]}
 
 
 def extras_one_gpu(eng, wl, orc, dev, torch) -> dict:
