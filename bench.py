@@ -219,9 +219,8 @@ def worker(args) -> int:
         # a fixed-base call above one pass (2^20 points with the 20-bit windows chosen from 2^20 points on,
         # MSM chunk in bn256msm.hip) runs as consecutive passes, one k_accumulate launch each; a blocking
         # call's phase times are summed over its passes, so kernel_ms covers all n points
-        pass_len = 1 << 20 if n >= (1 << 20) and not args.window_bits else 1 << 21
-        n_launch = min(n, pass_len) if not args.no_precompute else n
-        launches = -(-n // n_launch)
+        launches = passes_of(n, args)
+        n_launch = -(-n // launches)
         achieved = n * IMAD_PER_POINT / acc_s if acc_s > 0 else 0.0
         med = statistics.median(per_call) if per_call else float("nan")
         line = {
@@ -321,6 +320,7 @@ def worker(args) -> int:
         sync()
         if rank == 0:
             entry = {"points_total": 1 << 24, "points_per_gpu": big.n, "scaling": "strong",
+                     "passes_per_call": passes_of(big.n, args),
                      "steps": ksteps, "calls_in_flight": args.depth,
                      "ms_per_step": dtb / ksteps * 1e3, "points_per_s": (1 << 24) * ksteps / dtb,
                      "single_call_median_ms": statistics.median(calls) * 1e3,
@@ -347,6 +347,16 @@ def worker(args) -> int:
         dist.destroy_process_group()
     eng.close()
     return 0
+
+
+def passes_of(n: int, args) -> int:
+    """Passes (k_accumulate launches) of one fixed-base call of n points, as msm_enqueue_srcs plans them:
+    20-bit windows from 2^20 points on, passes of at most 9/8 x 2^20 points there, 2^21 below."""
+    if args.no_precompute:
+        return 1
+    wide = (n >= (1 << 20) and not args.window_bits) or args.window_bits == 20
+    pass_max = (1 << 20) * 9 // 8 if wide else 1 << 21
+    return -(-n // pass_max)
 
 
 def multi_ctx_leg(world: int, expect_hex: str) -> dict:

@@ -793,16 +793,30 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   const bool wide = precomp && c == 20;
   const size_t chunk_max = wide ? ((size_t)1 << 20) : ((size_t)1 << 30);
   const size_t chunk = std::min(ctx->msm_chunk ? ctx->msm_chunk : MSM_CHUNK, chunk_max);
-  // the passes: every term in sub-ranges of <= chunk points (table-less: the one term, one pass)
+  // The passes: every term in sub-ranges of about `chunk` points (table-less: the one term, one pass).
+  // Passes are balanced -- ceil(n / np) points each, rounded up to whole sort tiles -- and the wide path
+  // lets a pass grow to 9/8 of the chunk (its groups then average 30 k of the 32 k records pass B sorts in
+  // LDS): 2^20 + 9 points (the BP++ commitments' HVec, go/bppp/docs_test.go:560-564) are one pass, not a
+  // full one plus a 9-point one that pays every kernel's fixed cost again.
+  const size_t pass_max = wide ? chunk + chunk / 8 : chunk;
+  auto pass_len = [&](size_t n_term) -> size_t {  // points per pass of a term of n_term points
+    if (!precomp || n_term <= pass_max) return n_term;
+    const size_t np = (n_term + pass_max - 1) / pass_max;
+    const size_t len = ((n_term + np - 1) / np + SORT2_TILE - 1) / SORT2_TILE * SORT2_TILE;
+    return std::min(len, pass_max);
+  };
+  auto pass_count = [&](size_t n_term) -> size_t {
+    const size_t len = pass_len(n_term);
+    return len ? (n_term + len - 1) / len : 1;
+  };
   size_t npasses = 0, nmax = 0;
   for (int i = 0; i < nsrc; i++) {
     const msm_src& t = srcs[i];
     if (!t.n) continue;
     if ((t.b->levels > 1) != precomp || (precomp && (t.b->c != c || t.b->levels != W))) return BN256_EINVAL;
     if ((unsigned long long)t.b->n * t.b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
-    const size_t np = (precomp && t.n > chunk) ? (t.n + chunk - 1) / chunk : 1;
-    npasses += np;
-    nmax = std::max(nmax, np > 1 ? chunk : t.n);
+    npasses += pass_count(t.n);
+    nmax = std::max(nmax, pass_len(t.n));
   }
   const size_t nchunks = npasses;
   const unsigned long long entries_max = (unsigned long long)nmax * W;
@@ -836,7 +850,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   // 2^9..2^10 groups dominate
   const size_t two_min = (size_t)1 << (precomp ? 18 : 19);
   const bool two_pass =
-      wide ? (!ctx->sort1 && G2 == 512 && tiles2_max <= 1024 && nmax >= two_min && nmax <= ((size_t)1 << 20) &&
+      wide ? (!ctx->sort1 && G2 == 512 && tiles2_max <= 1024 && nmax >= two_min && nmax <= ((size_t)1 << 20) + ((size_t)1 << 17) &&
               entries_max <= (unsigned long long)G2 * 32768)
            : (c == 16 && nb == (1u << 15) && !ctx->sort1 && W <= 16 && G2 >= 1 && G2 <= 1024 && tiles2_max <= 1024 &&
               nmax >= two_min && entries_max <= (unsigned long long)G2 * 32768 &&
@@ -862,7 +876,9 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     // 2^14 points with a table 0.246 -> 0.213 ms, 2^12 without 0.186 -> 0.162 ms (more partial sums
     // for k_bucket_fix cost more than they save from 2^20 entries on)
     const unsigned long long kmin = e <= (1ull << 19) ? 8 : 16;
-    return ctx->tune_k ? (u32)ctx->tune_k : (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(kmin, e / 262144));
+    // rounded up: 2^18 threads are one round of waves, a 2^18 + 1st thread would run alone after them
+    return ctx->tune_k ? (u32)ctx->tune_k
+                       : (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(kmin, (e + 262143) / 262144));
   };
   auto threads_for = [&](size_t m) -> size_t {
     unsigned long long e = (unsigned long long)m * W;
@@ -871,8 +887,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   };
   size_t Tmax = threads_for(nmax);
   for (int i = 0; i < nsrc; i++) {  // a short last pass has a shorter chunk length and may have more threads
-    const size_t np = (precomp && srcs[i].n > chunk) ? (srcs[i].n + chunk - 1) / chunk : 1;
-    if (srcs[i].n) Tmax = std::max(Tmax, threads_for(srcs[i].n - (np - 1) * (np > 1 ? chunk : 0)));
+    if (srcs[i].n) Tmax = std::max(Tmax, threads_for(srcs[i].n - (pass_count(srcs[i].n) - 1) * pass_len(srcs[i].n)));
   }
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
@@ -925,7 +940,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
    const bn256_bases* b = t.b;
    const size_t stride = t.stride, sc_stride = t.sc_stride;
    const u32 top_scale = precomp ? b->top_scale : 1u;
-   const size_t np_t = (precomp && t.n > chunk) ? (t.n + chunk - 1) / chunk : 1, len_t = np_t > 1 ? chunk : t.n;
+   const size_t np_t = pass_count(t.n), len_t = pass_len(t.n);
    for (size_t cj = 0; cj < np_t; cj++, ch++) {
     const size_t n_ch = std::min(len_t, t.n - cj * len_t);
     const size_t off_ch = t.off + cj * len_t * stride;

@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
       }
       const u32 v = x >> LB;                       // (w << 11 | local) << 1 | sign
       const u32 local = (v >> 1) & 2047u, w = v >> 12;
-      r[it] = (((w << 20) | (lo_t * SORT2_TILE + local)) << 1) | (v & 1u);
+      r[it] = (((w << 21) | (lo_t * SORT2_TILE + local)) << 1) | (v & 1u);  // index in the pass < 2^21 (1024 tiles)
       kk[it] = x & (B - 1);
     }
   }
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
   for (u32 it = 0; it < SORT20_CAP / 1024; it++) {
     if (it * 1024 + threadIdx.x < m) {
       u32 pos = atomicAdd(&cur[kk[it]], 1u);
-      u32 idx = (r[it] >> 1) & 0xfffffu, w = r[it] >> 21;
+      u32 idx = (r[it] >> 1) & 0x1fffffu, w = r[it] >> 22;
       u32 tidx = w * level_stride + base_off + idx * pt_stride;
       stage[pos] = (tidx << 1) | (r[it] & 1u);
     }
@@ -869,10 +869,22 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
     if (e >= bend) {
       xyzz_store(head ? &partials[2 * (size_t)t] : &buckets[cur], acc);
       head = false;
+      u32 steps = 0;
       do {
         cur++;
         bend = offsets[cur + 1];
-      } while (e >= bend);
+      } while (e >= bend && ++steps < 8);
+      if (e >= bend) {
+        // many empty buckets in between (a sparse pass: a few points over 2^19 buckets would walk them
+        // one dependent load at a time -- 11 ms for a 9-point pass): first b > cur with offsets[b+1] > e
+        u32 lo = cur + 1, hi = nbt - 1;
+        while (lo < hi) {
+          u32 mid = (lo + hi) >> 1;
+          if (offsets[mid + 1] <= e) lo = mid + 1; else hi = mid;
+        }
+        cur = lo;
+        bend = offsets[cur + 1];
+      }
       xyzz_set_inf(acc);
       if (add_prev) xyzz_load(acc, &buckets[cur]);
     }

@@ -188,3 +188,21 @@ def test_default_window_choice_at_2_20_and_2_21(eng, orc):
         assert eng.msm_dev(h, v.device_ptr() + 32 * 45, m, off=45) == orc.synth_msm_closed_form(SEED_B, 0xC27, m, first=45)
         h.free()
         v.free()
+
+
+def test_pass_lengths_between_2_20_and_9_8ths(eng, orc):
+    """A wide pass may hold up to 9/8 x 2^20 points (2^20 + 9 is the BP++ commitments' HVec, one pass);
+    above that the passes are balanced.  The index field of the sort's registers holds 21 bits: a 20-bit
+    field sent indices >= 2^20 to the next table level (found as wrong sums and an out-of-bounds gather)."""
+    for n in ((1 << 20) + 9, (1 << 20) + 70000, (9 << 17), (9 << 17) + 1):
+        h = eng.random_bases(SEED_B, n, flags=crypto_amd.PRECOMPUTE)
+        s = bytearray(orc.synth_scalars(0xC29, n))
+        for skew in (False, True):
+            if skew:  # a quarter of the scalars in one bucket (oversized group, split sort, heavy bucket)
+                s[32 * (2 << 18):32 * (3 << 18)] = _be([1] * (1 << 18))
+            v = eng.fr_upload(bytes(s))
+            want = orc.synth_msm_closed_form_scalars(SEED_B, bytes(s))
+            assert eng.msm_dev(h, v.device_ptr(), n) == want
+            assert eng.msm_dev(h, v.device_ptr(), n) == want
+            v.free()
+        h.free()
