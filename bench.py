@@ -78,6 +78,17 @@ def cpu_baseline(sample_terms: int):
     return sample_terms / dt, orc
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def launcher(args) -> int:
     """The bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE): no GPU call here, N fresh ranks."""
     from crypto_amd import launch
@@ -301,6 +312,9 @@ def worker(args) -> int:
         line["cpu_baseline"] = {
             "value": v, "unit": "points/s", "cores": 1, "kind": "port",
             "device_result_matches_oracle_closed_form": bool(exact == result),
+            "host_cpu": cpu_model(),
+            # the algorithm is O(N): seconds for the full sizes from the sampled rate (extrapolated, not measured)
+            "extrapolated_seconds": {"2^20": (1 << 20) / v, "2^24": (1 << 24) / v},
             "sample": f"first {args.cpu_sample} terms of the same seeded workload, reference algorithm "
                       f"(per-term double-and-add + add, go/bp/util.go:165-175) restated in C, 1 thread",
         }
