@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <functional>
 #include <cstdio>
@@ -189,8 +190,8 @@ struct bn256_ctx {
   u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy), then the
                     // 1024 group totals of the two-pass sort: everything a pass needs zeroed, one memset
   u32* h_err;       // pinned
-  u32* d_flags;     // MSM_FLAG_* of the call in flight (kernels.cuh); h_flags: its pinned copy
-  u32* h_flags;
+  u32* d_flags;     // MSM_FLAG_* of the call in flight (kernels.cuh): the last two words of d_heavy's block; the
+                    // packing kernel appends them to the packed results, so they reach the host with h_pack
   int force_split;  // enqueue the split-sort kernels (set after a call met an oversized group, cleared after one that did not)
   int used_split;   // whether the pipeline enqueued last had them
   // bn256_msm_submit / bn256_msm_wait: each lane is a whole child context (own stream, workspaces,
@@ -288,8 +289,6 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->d_err) (void)hipFree(ctx->d_err);
   if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
-  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-  if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -300,18 +299,16 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
 static int ctx_init(bn256_ctx* ctx) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
-  for (int i = 0; i < 3; i++) {
-    hipError_t e = i == 0   ? pool::dev_malloc((void**)&ctx->d_err, 256)
-                   : i == 1 ? pool::dev_malloc((void**)&ctx->d_flags, 256)
-                            : pool::dev_malloc((void**)&ctx->d_heavy, (2 + HEAVY_SLOTS + 1024) * sizeof(u32));
+  for (int i = 0; i < 2; i++) {
+    hipError_t e = i == 0 ? pool::dev_malloc((void**)&ctx->d_err, 256)
+                          : pool::dev_malloc((void**)&ctx->d_heavy, HEAVY_WORDS * sizeof(u32));
     if (e != hipSuccess) {
       ctx_note_hip(e, __LINE__);
       return e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
     }
   }
+  ctx->d_flags = ctx->d_heavy + HEAVY_BASE;
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
-  HIPCHK(hipHostMalloc(&ctx->h_flags, 256));
-  ctx->h_flags[0] = 0;
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
   // the sort kernels' dynamic LDS above 48 KiB (per function and device; set here so that no MSM
@@ -760,7 +757,8 @@ struct msm_src {
 // Enqueues the device pipeline for the sum of `nsrc` such terms on ctx->stream, up to the copy of the
 // packed bucket sums into ctx->h_pack.  Several terms need fixed-base tables of one window width: they
 // share the single bucket set, every term contributes its passes (sub-ranges of <= MSM_CHUNK points),
-// k_add_buckets adds the passes' bucket sums and the reduction and host tail run ONCE -- the BP++
+// later passes add into the first pass's bucket sums (k_accumulate's add_prev) and the reduction and host
+// tail run ONCE -- the BP++
 // commitments <HVec, r||l> + <GVec, n> (go/bppp/docs_test.go:560-564) are one pipeline this way.
 // A table-less call has one term (callers gather several into one first).  With hold_stream the host
 // never waits for the stream here (a call of several passes then reports the phase times of its last
@@ -872,13 +870,20 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   // chunk length K of the accumulation kernel and its thread count for a pass of m points
   auto pick_k = [&](size_t m) -> u32 {
     unsigned long long e = (unsigned long long)m * W;
-    // >= 2^18 threads when there is work for them; short chunks (8) while the whole call is latency:
-    // 2^14 points with a table 0.246 -> 0.213 ms, 2^12 without 0.186 -> 0.162 ms (more partial sums
-    // for k_bucket_fix cost more than they save from 2^20 entries on)
-    const unsigned long long kmin = e <= (1ull << 19) ? 8 : 16;
-    // rounded up: 2^18 threads are one round of waves, a 2^18 + 1st thread would run alone after them
-    return ctx->tune_k ? (u32)ctx->tune_k
-                       : (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(kmin, (e + 262143) / 262144));
+    if (ctx->tune_k) return (u32)ctx->tune_k;
+    // >= 2^18 threads when there is work for them (rounded up: 2^18 threads are one round of waves, a
+    // 2^18 + 1st thread would run alone after them).  Up to 2^19 entries the whole call is latency: a thread's K
+    // mixed additions are a serial chain of ~7 us each (a lone wave), and a bucket of b entries then needs
+    // b / K quad additions of ~5 us in the fix-up, so K ~ 0.85 sqrt(b), as a power of two in [2, 16]
+    // (tools/ksweep_small.py: 64 points 0.27 -> 0.22 ms, 0.16 -> 0.14 with a table; 2^14 points without a
+    // table 0.43 -> 0.38).  Above that more partial sums cost more than they save: 16.
+    unsigned long long kmin = 16;
+    if (e <= (1ull << 19)) {
+      const double per_bucket = (double)e / (double)nbt;
+      kmin = 2;
+      while (kmin < 16 && (double)kmin < 0.85 * std::sqrt(per_bucket)) kmin <<= 1;
+    }
+    return (u32)std::min<unsigned long long>(4096, std::max<unsigned long long>(kmin, (e + 262143) / 262144));
   };
   auto threads_for = [&](size_t m) -> size_t {
     unsigned long long e = (unsigned long long)m * W;
@@ -900,8 +905,8 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   if ((rc = ws_reserve(ctx, WS_BUCKETS, nbt * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * Tmax * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_LASTB, Tmax * 4))) return rc;
-  if ((rc = ws_reserve(ctx, WS_PACK, npack * 32 * 4))) return rc;
-  if (npack * 32 * 4 > ctx->h_pack_cap) return BN256_EINVAL;
+  if ((rc = ws_reserve(ctx, WS_PACK, (npack * 32 + 2) * 4))) return rc;
+  if ((npack * 32 + 2) * 4 > ctx->h_pack_cap) return BN256_EINVAL;
 
   u32* counts = (u32*)ctx->ws[WS_COUNTS];
   u32* offsets = (u32*)ctx->ws[WS_OFFSETS];
@@ -930,8 +935,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   // call sees no oversized group).  flags[0]: oversized and unhandled; flags[1]: oversized, handled.
   const bool split = ctx->force_split != 0;
   ctx->used_split = split;
-  u32* d_flags = ctx->d_flags;
-  HIPCHK(hipMemsetAsync(d_flags, 0, 8, s));
+  u32* d_flags = ctx->d_flags;  // cleared with the first pass's counters below
 
   size_t ch = 0;  // running pass number over all terms
   for (int si = 0; si < nsrc; si++) {
@@ -958,11 +962,15 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     }
 
     MSM_MARK(0);
-    HIPCHK(hipMemsetAsync(heavy_count, 0, (2 + HEAVY_SLOTS + 1024) * sizeof(u32), s));
+    HIPCHK(hipMemsetAsync(heavy_count, 0, (ch == 0 ? HEAVY_WORDS : HEAVY_BASE) * sizeof(u32), s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
     const bool two = two_pass && n_ch >= two_min;
     auto scan = [&](const u32* in, u32* out, size_t m) {
+      if (m <= SCAN_SMALL_MAX) {  // one launch instead of three
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, in, out, (u32)m);
+        return;
+      }
       u32 nblk = nblocks(m, SCAN_TILE);
       hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(SCAN_BLOCK), 0, s, in, out, (u32)m, blocksum);
       hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, blocksum, nblk, blocksum + nblk);
@@ -1064,6 +1072,11 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     }
    }
   }
+  if (nb <= FOLD_SMALL_MAX_NB) {  // every level and the packing in one launch (small calls: launch-bound)
+    const u32 fold_threads = std::min<u32>(768u, std::max<u32>(64u, 2u * nb));  // nb / 2 quads at the widest level
+    hipLaunchKernelGGL(k_fold_small, dim3(nsets), dim3(fold_threads), 0, s, sum_buckets, nsets, nb, q, d_pack,
+                       (const u32*)d_flags);
+  } else {
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
     if (threads >= ((size_t)1 << 17)) {  // a level of that many independent additions is throughput work: lane per addition
@@ -1074,11 +1087,11 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, sum_buckets, nsets, nb, l);
   }
   hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)sum_buckets, nsets, nb, q,
-                     d_pack);
+                     d_pack, (const u32*)d_flags);
+  }
   MSM_MARK(6);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, npack * 32 * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(ctx->h_flags, d_flags, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, (npack * 32 + 2) * 4, hipMemcpyDeviceToHost, s));  // results + flags
   pend->empty = false;
   pend->c = c;
   pend->q = q;
@@ -1097,11 +1110,12 @@ static int msm_finish(bn256_ctx* ctx, const msm_pending* pend, hostg1::Pt* resul
   const int c = pend->c;
   const u32 q = pend->q, nsets = pend->nsets;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (ctx->h_flags[0] & MSM_FLAG_OVERSIZED) {  // see msm_enqueue_srcs: repeat with the split-sort kernels
+  const u32* h_flags = ctx->h_pack + (size_t)nsets * (q + 1) * 32;  // appended by the packing kernel
+  if (h_flags[0] & MSM_FLAG_OVERSIZED) {  // see msm_enqueue_srcs: repeat with the split-sort kernels
     ctx->force_split = 1;
     return MSM_RETRY;
   }
-  if (ctx->used_split && !ctx->h_flags[1]) ctx->force_split = 0;  // no oversized group this time
+  if (ctx->used_split && !h_flags[1]) ctx->force_split = 0;  // no oversized group this time
   for (int i = 0; i < 6 && pend->timed; i++) {
     float ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));

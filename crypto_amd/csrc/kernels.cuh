@@ -822,11 +822,38 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32
     if (base + j < n) out[base + j] += add;
 }
 
+// The same scan for up to SCAN_SMALL_MAX elements as ONE launch (small calls are bound by the number of
+// launches the host has to enqueue, ~4 us each, not by device time): 1024 threads x 16 elements.
+#define SCAN_SMALL_ITEMS 16
+#define SCAN_SMALL_MAX (1024 * SCAN_SMALL_ITEMS)
+__global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+  __shared__ u32 tmp[1024];
+  const u32 base = threadIdx.x * SCAN_SMALL_ITEMS;
+  u32 v[SCAN_SMALL_ITEMS];
+  u32 sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_SMALL_ITEMS; j++) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    sum += v[j];
+  }
+  u32 ex = block_exclusive_scan(sum, 1024, tmp);
+#pragma unroll
+  for (int j = 0; j < SCAN_SMALL_ITEMS; j++) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
 // ------------------------------------------------------------------ bucket accumulation
 #define FIX_CAP 32
 #define HEAVY_SPLIT_MIN 4096u  // partials above which one bucket is reduced by HEAVY_PARTS workgroups
 #define HEAVY_PARTS 64u
 #define HEAVY_SLOTS 1024u      // such buckets per pass (2T / 4096 <= 256 at the default chunk length)
+// The context's counter block: [0] heavy queue length, [1] split buckets, [2, 2 + HEAVY_SLOTS) tickets, 1024
+// group totals of the two-pass sort -- HEAVY_BASE words cleared before every pass -- then the two
+// MSM_FLAG words of the call, cleared with its first pass only (one memset either way).
+#define HEAVY_BASE (2u + HEAVY_SLOTS + 1024u)
+#define HEAVY_WORDS (HEAVY_BASE + 2u)
 // Thread t owns the sorted entries [t*K, (t+1)*K); bucket boundaries come from offsets[].
 // Runs of one bucket are summed with mixed additions.  A run that neither continues from
 // thread t-1 nor into thread t+1 is a complete bucket; otherwise it is a partial: slot 2t if
@@ -1122,29 +1149,10 @@ __global__ void __launch_bounds__(256) k_fold_lane(xyzz_mem* __restrict__ bucket
   }
 }
 
-// Canonical, non-Montgomery X,Y,ZZ,ZZZ (8 x u32 LE each) of T and G_k for the host tail.
-// total[b] += part[b], one quad per bucket (sub-range passes of one large MSM)
-__global__ void __launch_bounds__(64) k_add_buckets(xyzz_mem* __restrict__ total, const xyzz_mem* __restrict__ part,
-                                                    u32 nbt) {
-  u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 i = gid >> 2, role = gid & 3u;
-  if (i >= nbt) return;
-  xyzz a, b, r;
-  xyzz_load(a, &total[i]);
-  xyzz_load(b, &part[i]);
-  xyzz_add_quad(r, a, b, role);
-  if (role == 0) xyzz_store(&total[i], r);
-}
-
-__global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb,
-                                                     u32 q, u32* __restrict__ out) {
-  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= nsets * (q + 1)) return;
-  u32 set = tid / (q + 1), j = tid % (q + 1);
-  u32 idx = j == 0 ? 0u : (1u << (j - 1));
+// Canonical, non-Montgomery X,Y,ZZ,ZZZ (8 x u32 LE each) of one bucket for the host tail.
+__device__ __forceinline__ void pack_point(u32* __restrict__ o, const xyzz_mem* src) {
   xyzz a;
-  xyzz_load(a, buckets + (size_t)set * nb + idx);
-  u32* o = out + (size_t)tid * 32;
+  xyzz_load(a, src);
   fe* cs[4] = {&a.x, &a.y, &a.zz, &a.zzz};
   bool inf = xyzz_is_inf(a);
 #pragma unroll
@@ -1154,6 +1162,58 @@ __global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict_
     fe_pack256(w, c);
 #pragma unroll
     for (int m = 0; m < 8; m++) o[8 * k + m] = inf ? 0u : w[m];
+  }
+}
+// T and G_0..G_{q-1} of every bucket set for the host tail (out[set][j]: j = 0 T, j = k + 1 G_k), followed
+// by the call's two MSM_FLAG words: one device-to-host copy brings the host everything it needs.
+// (Folding the last ten levels of a 2^19-bucket reduction and this packing into one workgroup-resident
+// launch was measured: 99 us against 65 + 8 us for the launches.  A level is a quad addition's latency,
+// ~5 us for a lone wave that issues one v_mad_i64_i32 per ~9.6 clk, not launch overhead, and a single
+// workgroup needs two or three rounds for the wider levels.)
+__global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb,
+                                                     u32 q, u32* __restrict__ out, const u32* __restrict__ flags) {
+  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid == 0) {
+    out[(size_t)nsets * (q + 1) * 32] = flags[0];
+    out[(size_t)nsets * (q + 1) * 32 + 1] = flags[1];
+  }
+  if (tid >= nsets * (q + 1)) return;
+  u32 set = tid / (q + 1), j = tid % (q + 1);
+  pack_point(out + (size_t)tid * 32, buckets + (size_t)set * nb + (j == 0 ? 0u : (1u << (j - 1))));
+}
+
+// Small bucket sets (nb <= 512: the window widths of calls below ~2^16 points): every level of the
+// reduction and the packing in ONE launch, one workgroup per set, a __syncthreads() per level.  On the
+// device that is the same chain of quad additions as the q launches (the widest levels of a 512-bucket
+// set take two rounds of the 192 quads); the host enqueues one launch instead of q + 1, and a small call
+// is bound by exactly that.
+#define FOLD_SMALL_MAX_NB 512u
+__global__ void __launch_bounds__(768) k_fold_small(xyzz_mem* buckets, u32 nsets, u32 nb, u32 q, u32* __restrict__ out,
+                                                    const u32* __restrict__ flags) {
+  const u32 set = blockIdx.x;
+  xyzz_mem* B = buckets + (size_t)set * nb;
+  const u32 quad = threadIdx.x >> 2, role = threadIdx.x & 3u, nquads = blockDim.x >> 2;
+  for (u32 l = 0; l < q; l++) {
+    const u32 half = (nb >> l) >> 1;
+    const u32 items = (l + 1) * half;
+    for (u32 it = quad; it < items; it += nquads) {
+      const u32 row = it / half, i = it % half;
+      xyzz_mem* p = B + (row == 0 ? 0u : (nb >> row)) + i;
+      xyzz a, b, sum;
+      xyzz_load(a, p);
+      xyzz_load(b, p + half);
+      xyzz_add_quad(sum, a, b, role);
+      if (role == 0) xyzz_store(p, sum);
+    }
+    __syncthreads();  // the level's sums are in memory before the next level reads them (one workgroup, one CU)
+  }
+  if (set == 0 && threadIdx.x == 0) {
+    out[(size_t)nsets * (q + 1) * 32] = flags[0];
+    out[(size_t)nsets * (q + 1) * 32 + 1] = flags[1];
+  }
+  if (threadIdx.x <= q) {
+    const u32 j = threadIdx.x;
+    pack_point(out + ((size_t)set * (q + 1) + j) * 32, B + (j == 0 ? 0u : (1u << (j - 1))));
   }
 }
 
