@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip single_call / pcie / 2^24 / bulletproofs-like legs")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3], help="MSM calls in flight per GPU")
+    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3, 4], help="MSM calls in flight per GPU")
     return ap.parse_args(argv)
 
 
@@ -349,9 +349,21 @@ def worker(args) -> int:
         # (tools/multi_ctx_bench.py, a child of rank 0; the ranks wait at the barrier with their memory freed)
         if use_dist:
             dist.barrier()
+            torch.cuda.synchronize()
         if rank == 0:
             line["multi_device_ctx"] = multi_ctx_leg(world, resb.hex())
         if use_dist:
+            # the other ranks wait on the rendezvous store, on the CPU: an RCCL barrier would park a spinning
+            # kernel on every GPU the child is being timed on
+            try:
+                from datetime import timedelta
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set("bn256_multi_ctx_done", "1")
+                else:
+                    store.wait(["bn256_multi_ctx_done"], timedelta(seconds=400))
+            except Exception:  # noqa: BLE001 -- private accessor: fall back to the collective
+                pass
             dist.barrier()
 
     if rank == 0:
