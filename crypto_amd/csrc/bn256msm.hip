@@ -1051,14 +1051,14 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
                          (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
     MSM_MARK(4);
     if (by_chunks)
-      hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(T * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K,
-                         (const u32*)lastb, buckets, (const xyzz_mem*)partials, heavy_count, heavy_list,
-                         (const u32*)d_flags);
+      hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(std::min<size_t>(T, 262144), 256)), dim3(256), 0, s,
+                         (const u32*)offsets, (u32)nbt, K, (const u32*)lastb, buckets, (const xyzz_mem*)partials,
+                         heavy_count, heavy_list, (const u32*)d_flags);
     else
       hipLaunchKernelGGL(k_bucket_fix, dim3(nblocks(nbt * 4, 64)), dim3(64), 0, s, (const u32*)offsets, (u32)nbt, K,
                          add_prev, buckets, (const xyzz_mem*)partials, heavy_count, heavy_list, (const u32*)d_flags);
-    hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, K, buckets, (const xyzz_mem*)partials,
-                       heavy_count, (const u32*)heavy_list, (xyzz_mem*)ctx->ws[WS_HEAVYTMP]);
+    hipLaunchKernelGGL(k_heavy, dim3(256), dim3(256), 0, s, (const u32*)offsets, (u32)nbt, K, buckets,
+                       (const xyzz_mem*)partials, heavy_count, (const u32*)heavy_list, (xyzz_mem*)ctx->ws[WS_HEAVYTMP]);
     MSM_MARK(5);
     HIPCHK(hipGetLastError());  // a failed launch is reported with its own pass, not after all of them
     if (ch + 1 < nchunks && !hold_stream) {  // per-pass phase times; the last pass is read after the reduction

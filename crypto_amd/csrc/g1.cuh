@@ -172,10 +172,35 @@ __device__ __noinline__ xyzz xyzz_madd_special(fe x2, fe y2, fe rr) {
   }
   return r;
 }
-__device__ __noinline__ xyzz xyzz_dbl_outofline(xyzz a) {
-  xyzz r;
-  xyzz_dbl(r, a);
-  return r;
+// The doubling inside a general addition (P == Q) goes through the caller's stack, one out-of-line
+// multiplication at a time: passed by value, its 72 argument and result registers (and, inlined, its nine
+// multiplications' live ranges) set the register budget of every kernel that can reach it -- 161 VGPRs,
+// three waves per SIMD instead of four -- for a path that random inputs never take.  The caller copies
+// the operand into a temporary inside the rare branch only, so its own operands stay in registers.
+// Same formulas and operand ranges as xyzz_dbl_quad (dbl-2008-s-1).
+__device__ __noinline__ void fe_mul_mem(fe* r, const fe* a, const fe* b) {
+  fe x = *a, y = *b;
+  *r = fe_mul(x, y);
+}
+__device__ __noinline__ void xyzz_dbl_outofline(xyzz* io) {
+  if (xyzz_is_inf(*io)) return;
+  fe yy, v, t, w, s, xx, m, mm, x3, d, t1, t2;
+  fe_mul_mem(&yy, &io->y, &io->y);
+  v = fe_norm(fe_small_mul(yy, 4));
+  fe_mul_mem(&t, &io->y, &v);
+  w = fe_norm(fe_add(t, t));
+  fe_mul_mem(&s, &io->x, &v);
+  fe_mul_mem(&xx, &io->x, &io->x);
+  m = fe_norm(fe_small_mul(xx, 3));
+  fe_mul_mem(&mm, &m, &m);
+  x3 = fe_norm(fe_sub(fe_sub(mm, s), s));
+  d = fe_sub(s, x3);
+  fe_mul_mem(&t1, &m, &d);
+  fe_mul_mem(&t2, &w, &io->y);
+  fe_mul_mem(&io->zz, &v, &io->zz);
+  fe_mul_mem(&io->zzz, &w, &io->zzz);
+  io->x = x3;
+  io->y = fe_norm(fe_sub(t1, t2));
 }
 
 // acc += (x2, y2), affine operand not at infinity (madd-2008-s): 8M + 2S.
@@ -226,7 +251,9 @@ __device__ __forceinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) 
   if (fe_maybe_zero_sq(pp)) {
     if (fe_is_zero_mod_p(h)) {
       if (fe_is_zero_mod_p(rr)) {
-        r = xyzz_dbl_outofline(a);
+        xyzz tmp = a;
+        xyzz_dbl_outofline(&tmp);
+        r = tmp;
       } else {
         xyzz_set_inf(r);
       }
@@ -288,7 +315,9 @@ __device__ __forceinline__ void xyzz_add_quad(xyzz& r, const xyzz& a, const xyzz
   if (fe_maybe_zero_sq(pp)) {
     if (fe_is_zero_mod_p(h)) {  // P == +-Q: rare, every lane takes the serial path
       if (fe_is_zero_mod_p(rr)) {
-        r = xyzz_dbl_outofline(a);
+        xyzz tmp = a;
+        xyzz_dbl_outofline(&tmp);
+        r = tmp;
       } else {
         xyzz_set_inf(r);
       }

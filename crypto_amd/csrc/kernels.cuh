@@ -852,7 +852,8 @@ __global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in,
 // The context's counter block: [0] heavy queue length, [1] split buckets, [2, 2 + HEAVY_SLOTS) tickets, 1024
 // group totals of the two-pass sort -- HEAVY_BASE words cleared before every pass -- then the two
 // MSM_FLAG words of the call, cleared with its first pass only (one memset either way).
-#define HEAVY_BASE (2u + HEAVY_SLOTS + 1024u)
+#define HEAVY_MEDIUM (2u + HEAVY_SLOTS + 1024u)  // length of the medium queue (k_fix_boundary)
+#define HEAVY_BASE (HEAVY_MEDIUM + 2u)
 #define HEAVY_WORDS (HEAVY_BASE + 2u)
 // Thread t owns the sorted entries [t*K, (t+1)*K); bucket boundaries come from offsets[].
 // Runs of one bucket are summed with mixed additions.  A run that neither continues from
@@ -930,47 +931,52 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
 }
 
 // The fix-up seen from the chunks instead of the buckets (dense passes: far fewer chunk boundaries than
-// buckets): quad t looks at the bucket its chunk's last run belongs to; if that bucket starts in
-// chunk t and runs on into the next chunks, this quad joins its partial sums (slot 2 t + 1, then
-// 2 t' for the chunks it covers) exactly as k_bucket_fix does.  Buckets without entries were set to
-// infinity by the sort kernels.
-__global__ void __launch_bounds__(64) k_fix_boundary(const u32* __restrict__ offsets, u32 nbt, u32 K,
-                                                     const u32* __restrict__ lastb, xyzz_mem* __restrict__ buckets,
-                                                     const xyzz_mem* __restrict__ partials,
-                                                     u32* __restrict__ heavy_count, u32* __restrict__ heavy_list,
-                                                     const u32* __restrict__ flags) {
+// buckets): lane t looks at the bucket its chunk's last run belongs to; if that bucket starts in
+// chunk t and runs on into the next chunks, this lane joins its partial sums (slot 2 t + 1, then
+// 2 t' for the chunks it covers).  With ~26 entries per bucket and 52 per chunk nearly every chunk
+// boundary falls inside a bucket: 2^18 independent additions, throughput work, one LANE each (the quad
+// form spends 2.3x the machine time on them, which shows once several calls share the chip).  Chains of
+// more than FIX_LANE_CAP partial sums (skewed scalars) go to the medium queue, which k_heavy's quads work
+// off as serial chains, those above FIX_CAP to the heavy queue.  Buckets without entries were set to
+// infinity by the sort.
+#define FIX_LANE_CAP 3u
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_fix_boundary(const u32* __restrict__ offsets, u32 nbt, u32 K, const u32* __restrict__ lastb,
+               xyzz_mem* __restrict__ buckets, const xyzz_mem* __restrict__ partials, u32* __restrict__ heavy_count,
+               u32* __restrict__ heavy_list, const u32* __restrict__ flags) {
   if (flags[0] & MSM_FLAG_OVERSIZED) return;
-  u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
-  u32 t0 = tid >> 2, role = tid & 3u;
-  if ((u64)t0 * K >= offsets[nbt]) return;
-  u32 v = lastb[t0];
-  if (!(v >> 31)) return;             // the chunk's last run ends inside the chunk
-  u32 b = v & 0x7fffffffu;
-  u32 lo = offsets[b], hi = offsets[b + 1];
-  if ((u64)lo < (u64)t0 * K) return;  // the bucket started in an earlier chunk: that chunk's quad has it
-  u32 t1 = (hi - 1) / K;
-  if (t1 - t0 + 1 > FIX_CAP) {
-    if (role == 0) {
+  const u32 M = offsets[nbt];
+  const u32 nchunks = M / K + (M % K ? 1u : 0u), step = gridDim.x * blockDim.x;
+  for (u32 t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < nchunks; t0 += step) {
+    u32 v = lastb[t0];
+    if (!(v >> 31)) continue;             // the chunk's last run ends inside the chunk
+    u32 b = v & 0x7fffffffu;
+    u32 lo = offsets[b], hi = offsets[b + 1];
+    if ((u64)lo < (u64)t0 * K) continue;  // the bucket started in an earlier chunk: that chunk's lane has it
+    u32 t1 = (hi - 1) / K, np = t1 - t0 + 1;
+    if (np > FIX_CAP) {
       u32 ent = b;
-      if (t1 - t0 + 1 > HEAVY_SPLIT_MIN && b < (1u << 20)) {
+      if (np > HEAVY_SPLIT_MIN && b < (1u << 20)) {
         u32 slot = atomicAdd(heavy_count + 1, 1u);
         if (slot < HEAVY_SLOTS) ent = b | 0x80000000u | (slot << 20);
       }
       heavy_list[atomicAdd(heavy_count, 1u)] = ent;
+      continue;
     }
-    return;
+    if (np > FIX_LANE_CAP) {  // the medium queue grows from the end of the list
+      heavy_list[nbt - 1u - atomicAdd(heavy_count + HEAVY_MEDIUM, 1u)] = b;
+      continue;
+    }
+    xyzz acc;
+    xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
+    for (u32 t = t0 + 1; t <= t1; t++) {
+      xyzz p, r;
+      xyzz_load(p, &partials[2 * (size_t)t]);
+      xyzz_add(r, acc, p);
+      acc = r;
+    }
+    xyzz_store(&buckets[b], acc);
   }
-  xyzz acc, p;
-  xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
-  xyzz_load(p, &partials[2 * (size_t)(t0 + 1)]);
-  for (u32 t = t0 + 1; t <= t1; t++) {
-    xyzz pn, r;
-    if (t < t1) xyzz_load(pn, &partials[2 * (size_t)(t + 1)]);
-    xyzz_add_quad(r, acc, p, role);
-    acc = r;
-    p = pn;
-  }
-  if (role == 0) xyzz_store(&buckets[b], acc);
 }
 
 // One thread per bucket: empty buckets become infinity; buckets that straddle chunks
@@ -1056,11 +1062,31 @@ __device__ __forceinline__ void heavy_reduce(xyzz& acc, const xyzz_mem* __restri
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, u32 K, xyzz_mem* __restrict__ buckets,
+__global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, u32 nbt, u32 K,
+                                               xyzz_mem* __restrict__ buckets,
                                                const xyzz_mem* __restrict__ partials, u32* __restrict__ heavy_count,
                                                const u32* __restrict__ heavy_list, xyzz_mem* __restrict__ tmp) {
   __shared__ xyzz_mem sh[64];
   __shared__ u32 ticket;
+  const u32 nmed = heavy_count[HEAVY_MEDIUM];
+  if (nmed) {  // the medium queue (k_fix_boundary): one quad per bucket, its partial sums as a serial chain
+    const u32 role = threadIdx.x & 3u, nquads = (gridDim.x * blockDim.x) >> 2;
+    for (u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < nmed; i += nquads) {
+      const u32 b = heavy_list[nbt - 1u - i];
+      const u32 t0 = offsets[b] / K, t1 = (offsets[b + 1] - 1) / K;
+      xyzz acc, p;
+      xyzz_load(acc, &partials[2 * (size_t)t0 + 1]);
+      xyzz_load(p, &partials[2 * (size_t)(t0 + 1)]);
+      for (u32 t = t0 + 1; t <= t1; t++) {
+        xyzz pn, r;
+        if (t < t1) xyzz_load(pn, &partials[2 * (size_t)(t + 1)]);
+        xyzz_add_quad(r, acc, p, role);
+        acc = r;
+        p = pn;
+      }
+      if (role == 0) xyzz_store(&buckets[b], acc);
+    }
+  }
   const u32 nheavy = heavy_count[0];
   u32* tickets = heavy_count + 2;
   // items are part-major (part 0 of every entry first) so that ordinary heavy buckets spread over
