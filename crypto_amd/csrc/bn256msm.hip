@@ -174,6 +174,8 @@ enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM
 struct bn256_ctx {
   int device;
   hipStream_t stream;
+  hipStream_t copy_stream;  // scalar uploads of bn256_msm, pass by pass, beside the stream's kernels
+  hipEvent_t ev_copy[2];
   void* ws[WS_COUNT];
   size_t cap[WS_COUNT];
   hipEvent_t ev[8];
@@ -291,6 +293,9 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
   if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
   if (ctx->h_err) (void)hipHostFree(ctx->h_err);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+  for (auto& e : ctx->ev_copy)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (counted) pool::context_destroyed();
   delete ctx;
@@ -752,6 +757,11 @@ struct msm_src {
   size_t off, stride, n;
   const uint8_t* sc;
   size_t sc_stride;
+  // bn256_msm: the term's scalars are still in HOST memory here (n x 32 bytes, sc_stride 1) and `sc` is
+  // where they go.  Every pass uploads its own slice on the context's copy stream, the next pass's while
+  // this pass's kernels run, and a fixed-base term of >= 2^19 points is cut in at least two passes for
+  // that: the call's PCIe time hides behind its own compute instead of preceding it.
+  const uint8_t* host_sc = nullptr;
 };
 
 // Enqueues the device pipeline for the sum of `nsrc` such terms on ctx->stream, up to the copy of the
@@ -797,15 +807,17 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   // LDS): 2^20 + 9 points (the BP++ commitments' HVec, go/bppp/docs_test.go:560-564) are one pass, not a
   // full one plus a 9-point one that pays every kernel's fixed cost again.
   const size_t pass_max = wide ? chunk + chunk / 8 : chunk;
-  auto pass_len = [&](size_t n_term) -> size_t {  // points per pass of a term of n_term points
-    if (!precomp || n_term <= pass_max) return n_term;
-    const size_t np = (n_term + pass_max - 1) / pass_max;
+  auto pass_len = [&](const msm_src& t) -> size_t {  // points per pass of a term
+    const size_t n_term = t.n;
+    const bool split_upload = t.host_sc && precomp && n_term >= ((size_t)1 << 19);
+    if (!precomp || (n_term <= pass_max && !split_upload)) return n_term;
+    const size_t np = std::max<size_t>((n_term + pass_max - 1) / pass_max, split_upload ? 2 : 1);
     const size_t len = ((n_term + np - 1) / np + SORT2_TILE - 1) / SORT2_TILE * SORT2_TILE;
     return std::min(len, pass_max);
   };
-  auto pass_count = [&](size_t n_term) -> size_t {
-    const size_t len = pass_len(n_term);
-    return len ? (n_term + len - 1) / len : 1;
+  auto pass_count = [&](const msm_src& t) -> size_t {
+    const size_t len = pass_len(t);
+    return len ? (t.n + len - 1) / len : 1;
   };
   size_t npasses = 0, nmax = 0;
   for (int i = 0; i < nsrc; i++) {
@@ -813,8 +825,9 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     if (!t.n) continue;
     if ((t.b->levels > 1) != precomp || (precomp && (t.b->c != c || t.b->levels != W))) return BN256_EINVAL;
     if ((unsigned long long)t.b->n * t.b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
-    npasses += pass_count(t.n);
-    nmax = std::max(nmax, pass_len(t.n));
+    if (t.host_sc && t.sc_stride != 1) return BN256_EINVAL;
+    npasses += pass_count(t);
+    nmax = std::max(nmax, pass_len(t));
   }
   const size_t nchunks = npasses;
   const unsigned long long entries_max = (unsigned long long)nmax * W;
@@ -892,7 +905,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   };
   size_t Tmax = threads_for(nmax);
   for (int i = 0; i < nsrc; i++) {  // a short last pass has a shorter chunk length and may have more threads
-    if (srcs[i].n) Tmax = std::max(Tmax, threads_for(srcs[i].n - (pass_count(srcs[i].n) - 1) * pass_len(srcs[i].n)));
+    if (srcs[i].n) Tmax = std::max(Tmax, threads_for(srcs[i].n - (pass_count(srcs[i]) - 1) * pass_len(srcs[i])));
   }
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
@@ -944,7 +957,22 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
    const bn256_bases* b = t.b;
    const size_t stride = t.stride, sc_stride = t.sc_stride;
    const u32 top_scale = precomp ? b->top_scale : 1u;
-   const size_t np_t = pass_count(t.n), len_t = pass_len(t.n);
+   const size_t np_t = pass_count(t), len_t = pass_len(t);
+   // the upload of pass j's scalars (host_sc terms): issued once, at the latest when the pass starts
+   size_t uploaded = 0;
+   auto upload_pass = [&](size_t j) -> int {
+     if (!t.host_sc || j >= np_t || j < uploaded) return BN256_OK;
+     if (!ctx->copy_stream) {  // made at the first call with host scalars (lanes and device-pointer callers never need it)
+       HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+       for (auto& e : ctx->ev_copy) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+     }
+     const size_t first = j * len_t, len = std::min(len_t, t.n - first);
+     HIPCHK(hipMemcpyAsync((uint8_t*)t.sc + first * 32, t.host_sc + first * 32, len * 32, hipMemcpyHostToDevice,
+                           ctx->copy_stream));
+     HIPCHK(hipEventRecord(ctx->ev_copy[j & 1], ctx->copy_stream));
+     uploaded = j + 1;
+     return BN256_OK;
+   };
    for (size_t cj = 0; cj < np_t; cj++, ch++) {
     const size_t n_ch = std::min(len_t, t.n - cj * len_t);
     const size_t off_ch = t.off + cj * len_t * stride;
@@ -961,6 +989,10 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       ntiles = (u32)((n_ch + tile_len - 1) / tile_len);
     }
 
+    if (t.host_sc) {  // this pass's scalars: uploaded on the copy stream (issued during the previous pass)
+      if ((rc = upload_pass(cj))) return rc;
+      HIPCHK(hipStreamWaitEvent(s, ctx->ev_copy[cj & 1], 0));
+    }
     MSM_MARK(0);
     HIPCHK(hipMemsetAsync(heavy_count, 0, (ch == 0 ? HEAVY_WORDS : HEAVY_BASE) * sizeof(u32), s));
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
@@ -1061,7 +1093,10 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
                        (const xyzz_mem*)partials, heavy_count, (const u32*)heavy_list, (xyzz_mem*)ctx->ws[WS_HEAVYTMP]);
     MSM_MARK(5);
     HIPCHK(hipGetLastError());  // a failed launch is reported with its own pass, not after all of them
-    if (ch + 1 < nchunks && !hold_stream) {  // per-pass phase times; the last pass is read after the reduction
+    if ((rc = upload_pass(cj + 1))) return rc;  // the next pass's scalars cross PCIe under this pass's kernels
+    // per-pass phase times (the last pass is read after the reduction); not with host scalars: the wait
+    // would keep the next pass's kernels from being enqueued under this pass
+    if (ch + 1 < nchunks && !hold_stream && !t.host_sc) {
       HIPCHK(hipStreamSynchronize(s));
       for (int i = 0; i < 5; i++) {
         float ms;
@@ -1144,12 +1179,18 @@ static int msm_enqueue(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t 
 }
 
 static int msm_core(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n,
-                    const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1) {
+                    const uint8_t* d_scalars, hostg1::Pt* result, size_t sc_stride = 1,
+                    const uint8_t* host_scalars = nullptr) {
   *result = hostg1::infinity();
   for (;;) {
     msm_pending pend;
-    int rc = msm_enqueue(ctx, b, off, stride, n, d_scalars, sc_stride, false, &pend);
-    if (rc) return rc;
+    msm_src one = {b, off, stride, n, d_scalars, sc_stride};
+    one.host_sc = host_scalars;
+    int rc = msm_enqueue_srcs(ctx, &one, 1, false, &pend);
+    if (rc) {
+      if (host_scalars && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);  // no copy may outlive the caller's buffer
+      return rc;
+    }
     if ((rc = msm_finish(ctx, &pend, result)) != MSM_RETRY) return rc;
   }
 }
@@ -1261,11 +1302,9 @@ static int msm_host_scalars(bn256_ctx* ctx, const bn256_bases* b, size_t off, si
                             const uint8_t* scalars_be, hostg1::Pt* r) {
   int rc = range_check(b, off, n, stride);
   if (rc) return rc;
-  if (n) {
-    if ((rc = ws_reserve(ctx, WS_SCALARS, n * 32))) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  }
-  return msm_core(ctx, b, off, stride, n, (const uint8_t*)ctx->ws[WS_SCALARS], r);
+  if (n && (rc = ws_reserve(ctx, WS_SCALARS, n * 32))) return rc;
+  // the upload is part of the pipeline (msm_src::host_sc): pass by pass on the copy stream
+  return msm_core(ctx, b, off, stride, n, (const uint8_t*)ctx->ws[WS_SCALARS], r, 1, n ? scalars_be : nullptr);
 }
 
 extern "C" int bn256_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars_be,
