@@ -759,7 +759,7 @@ struct msm_src {
   size_t sc_stride;
   // bn256_msm: the term's scalars are still in HOST memory here (n x 32 bytes, sc_stride 1) and `sc` is
   // where they go.  Every pass uploads its own slice on the context's copy stream, the next pass's while
-  // this pass's kernels run, and a fixed-base term of >= 2^19 points is cut in at least two passes for
+  // this pass's kernels run, and a fixed-base term of >= 2^20 points is cut in at least two passes for
   // that: the call's PCIe time hides behind its own compute instead of preceding it.
   const uint8_t* host_sc = nullptr;
 };
@@ -809,7 +809,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   const size_t pass_max = wide ? chunk + chunk / 8 : chunk;
   auto pass_len = [&](const msm_src& t) -> size_t {  // points per pass of a term
     const size_t n_term = t.n;
-    const bool split_upload = t.host_sc && precomp && n_term >= ((size_t)1 << 19);
+    const bool split_upload = t.host_sc && precomp && n_term >= ((size_t)1 << 20);  // below, two passes cost what they hide
     if (!precomp || (n_term <= pass_max && !split_upload)) return n_term;
     const size_t np = std::max<size_t>((n_term + pass_max - 1) / pass_max, split_upload ? 2 : 1);
     const size_t len = ((n_term + np - 1) / np + SORT2_TILE - 1) / SORT2_TILE * SORT2_TILE;
