@@ -99,3 +99,37 @@ def test_random_calls_against_the_closed_form(orc, seed):
             h.free()
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_calls_on_a_multi_device_context(orc, seed):
+    """The same against bn256_ctx_create_multi (two or three shards on the box's one device): ranges that
+    start, end or lie inside any shard, host scalars, device pointer, resident vector."""
+    rng = random.Random(0xD0D0 + seed)
+    e = crypto_amd.Engine(devices=[0] * rng.choice((2, 3)))
+    try:
+        for case in range(10):
+            table = rng.random() < 0.5
+            size = int(2 ** rng.uniform(0, 17)) + rng.randrange(3)
+            seed_b = 0xCD00 + 100 * seed + case
+            h = e.random_bases(seed_b, size, flags=crypto_amd.PRECOMPUTE if table else 0)
+            ks = orc.synth_base_scalars(seed_b, size)
+            off = rng.randrange(size)
+            n = rng.randrange(0, size - off + 1)
+            a = _scalars(rng, rng.choice(("uniform", "few", "bits", "edge")), n)
+            kind = rng.choice(("host", "dev", "fr"))
+            if kind == "host":
+                got = e.msm(h, _be(a), off=off, n=n)
+            else:
+                v = e.fr_upload(_be(x % N for x in a)) if n else None
+                if kind == "dev":
+                    got = e.msm_dev(h, v.device_ptr() if n else 0, n, off=off)
+                else:
+                    got = e.msm_fr(h, off, 1, n, v) if n else bytes(64)
+                if v:
+                    v.free()
+            want = orc.fr_dot(_be(x % N for x in a), ks[32 * off:32 * (off + n)]) if n else 0
+            assert got == orc.g0_mul(want), f"seed {seed} case {case}: size {size} table {table} {kind} off {off} n {n}"
+            h.free()
+    finally:
+        e.close()
