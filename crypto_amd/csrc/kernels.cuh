@@ -569,6 +569,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
   __syncthreads();
   // the thread's records move to registers: (window | tile * 2048 + local | sign) and the low key bits
   u32 r[SORT20_CAP / 1024], kk[SORT20_CAP / 1024];
+  const float tiles_per_record = m ? (float)ntiles / (float)m : 0.f;
 #pragma unroll
   for (u32 it = 0; it < SORT20_CAP / 1024; it++) {
     const u32 e = it * 1024 + threadIdx.x;
@@ -576,11 +577,22 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
     kk[it] = 0;
     if (e < m) {
       const u32 x = stage[e];
-      // tile = first t with run_end[t] > e (ntiles <= 1024: ten steps)
-      u32 lo_t = 0, hi_t = ntiles - 1;
-      while (lo_t < hi_t) {
-        const u32 mid = (lo_t + hi_t) >> 1;
-        if (run_end[mid] <= e) lo_t = mid + 1; else hi_t = mid;
+      // tile = first t with run_end[t] > e.  Uniform scalars give every tile the same share of the group, so
+      // e * ntiles / m is right to within a tile or two: a short walk from there (two or three LDS reads
+      // instead of a ten-step binary search per record), the search only when the walk does not arrive
+      // (skewed scalars)
+      u32 lo_t = (u32)((float)e * tiles_per_record);  // a guess: any value is corrected below
+      if (lo_t > ntiles - 1) lo_t = ntiles - 1;
+      u32 steps = 0;
+      while (lo_t > 0 && run_end[lo_t - 1] > e && steps < 6) { lo_t--; steps++; }
+      while (run_end[lo_t] <= e && lo_t < ntiles - 1 && steps < 6) { lo_t++; steps++; }
+      if (steps >= 6) {
+        u32 hi_t = ntiles - 1;
+        lo_t = 0;
+        while (lo_t < hi_t) {
+          const u32 mid = (lo_t + hi_t) >> 1;
+          if (run_end[mid] <= e) lo_t = mid + 1; else hi_t = mid;
+        }
       }
       const u32 v = x >> LB;                       // (w << 11 | local) << 1 | sign
       const u32 local = (v >> 1) & 2047u, w = v >> 12;
