@@ -1,14 +1,19 @@
 // HIP kernels of the BN256 G1 MSM engine (gfx950).  Pipeline of one MSM
 // (vectorPointScalarMul, go/bp/util.go:165-175, go/bppp/util.go:178-196):
 //
-//   k_part, k_group_sort        two-pass LDS-staged bucket sort (fixed-base, >= 2^18 points); otherwise:
+//   k_part<16|20>, k_group_sort(_tl)  two-pass LDS-staged bucket sort (>= 2^18 points; _tl: the 20-bit-window
+//                     path's tile-local records); k_group_count/subscan/place: groups larger than LDS.  Otherwise:
 //   k_tile_sort<0>    signed c-bit digits of every scalar, per-tile LDS bucket histograms
-//   k_tile_scan       per-bucket prefix over tiles;  k_scan1/2/3: bucket totals -> bucket offsets
+//   k_tile_scan       per-bucket prefix over tiles;  k_scan1/2/3 or k_scan_small: bucket totals -> offsets
 //   k_tile_sort<1>    LDS cursors, scatter of (base index|sign) into bucket order (counting sort)
+//   k_recode<0|1>     the same two steps with global atomics, for bucket sets that do not fit LDS
 //   k_accumulate      balanced segmented bucket accumulation, XYZZ mixed additions
-//   k_bucket_fix      joins the partial sums of buckets that straddle thread chunks
-//   k_fold            log-depth bucket reduction: T = sum B_b and G_k = sum_{bit k of b} B_b
+//   k_bucket_fix      joins the partial sums of buckets that straddle thread chunks (quad per bucket);
+//   k_fix_boundary    the same seen from the chunk boundaries (lane per boundary; 2^19 buckets);
+//   k_heavy           buckets with many partial sums (skewed scalars)
+//   k_fold_lane, k_fold   log-depth bucket reduction: T = sum B_b and G_k = sum_{bit k of b} B_b
 //   k_pack_results    canonical XYZZ words of T, G_0..G_{c-2} for the host Horner tail
+//   k_fold_small      all levels and the packing of a <= 512-bucket set in one launch
 //
 // Element-wise companions: k_points_from_be / k_points_to_be (Unmarshal / Marshal),
 // k_precompute_level (2^c * P), k_scalar_mul (vectorPointMulOnScalar and the h1 loop,
