@@ -199,16 +199,23 @@ def worker(args) -> int:
     dt, result = wl.timed(args.steps, args.depth)
     steps = max(args.steps, 1)
     host_timed = [x / steps for x in host_us]
-    # The same K steps as strictly blocking calls (not part of `value`).  The per-phase HIP events and
-    # the roofline's kernel time are taken here: with several calls in flight an event pair also spans
+    # The same K steps as strictly blocking calls (not part of `value`), twice: first as a caller makes them
+    # (`single_call`: wall time per call), then with the library's per-phase HIP events switched on
+    # (bn256_ctx_set_phase_timing: the events cost 1-2.5 % of such a call, so they are off by default) for
+    # `phases_ms` and the roofline's kernel time.  With several calls in flight an event pair would also span
     # the time a kernel waits behind the other call's kernels, which is not kernel time.
     phase = [0.0] * 7
     nblk = max(args.steps, 10)
     wl.run(2, 1)
     sync()
-    per_call, result_blocking = wl.blocking_calls(nblk, phase)
+    per_call, result_blocking = wl.blocking_calls(nblk)
     sync()
     dt_blocking = sum(per_call)
+    eng.set_phase_timing(True)
+    wl.blocking_calls(2)
+    wl.blocking_calls(nblk, phase)
+    eng.set_phase_timing(False)
+    sync()
 
     line = None
     if rank == 0:
@@ -278,7 +285,7 @@ def worker(args) -> int:
                 "launches_per_call": launches,
                 "points_per_launch": n_launch,
                 "measured_over": f"{nblk} blocking calls after the timed region (one call on the chip at a time), "
-                                 f"HIP events on the call's own stream",
+                                 f"the library's HIP events on the call's own stream (switched on for these calls only)",
                 "achieved": achieved,
                 "peak": IMAD_PEAK,
                 "unit": "IMAD/s",

@@ -12,7 +12,7 @@ EXPORTS = [
     "bn256_ctx_create", "bn256_ctx_create_multi", "bn256_ctx_destroy", "bn256_ctx_stream", "bn256_bases_upload", "bn256_bases_free",
     "bn256_bases_len", "bn256_msm", "bn256_msm_dev", "bn256_msm_dev_noalloc", "bn256_msm_submit", "bn256_msm_wait", "bn256_msm_multi", "bn256_msm_multi_strided", "bn256_fold2", "bn256_scalar_mul_batch",
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
-    "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
+    "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_ctx_set_phase_timing", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
     "bn256_fr_fold", "bn256_fr_dot", "bn256_fr_fold_multi", "bn256_fr_dot_multi", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait", "bn256_ctx_drain",
 ]
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     lib.bn256_glv_split.argtypes = [u8p, u8p, C.POINTER(C.c_int), u8p, C.POINTER(C.c_int)]
     lib.bn256_g1_sum.argtypes = [u8p, sz, u8p]
     lib.bn256_ctx_set_tuning.argtypes = [vp, i, i]
+    lib.bn256_ctx_set_phase_timing.argtypes = [vp, i]
     lib.bn256_last_timing.argtypes = [vp, C.POINTER(C.c_float), i]
     lib.bn256_selftest.argtypes = [vp]
     lib.bn256_strerror.argtypes = [i]

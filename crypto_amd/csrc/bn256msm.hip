@@ -181,6 +181,7 @@ struct bn256_ctx {
   hipEvent_t ev[8];
   float last_ms[7];
   int tune_c, tune_k;
+  int phase_timing;  // bn256_ctx_set_phase_timing: record the per-phase events of bn256_last_timing
   size_t msm_chunk;  // 0 = MSM_CHUNK; BN256_MSM_CHUNK_LOG2 in the environment overrides (experiments)
   int sort1;         // BN256_SORT1=1 forces the single-pass sort (experiments)
   // bn256_msm_dev_noalloc: while set, ws_reserve carves ws[] from the device's static scratch array
@@ -395,6 +396,13 @@ extern "C" int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk) 
   }
   ctx->tune_c = window_bits;
   ctx->tune_k = chunk;
+  return BN256_OK;
+}
+
+extern "C" int bn256_ctx_set_phase_timing(bn256_ctx* ctx, int on) {
+  if (!ctx) return BN256_EINVAL;
+  for (int s = 0; s < ctx->nshard; s++) ctx->shard[s]->phase_timing = on != 0;
+  ctx->phase_timing = on != 0;
   return BN256_OK;
 }
 
@@ -683,6 +691,7 @@ static int lane_acquire(bn256_ctx* ctx, int* out) {
   }
   ctx->lane[l]->tune_c = ctx->tune_c;
   ctx->lane[l]->tune_k = ctx->tune_k;
+  ctx->lane[l]->phase_timing = ctx->phase_timing;
   *out = l;
   return BN256_OK;
 }
@@ -934,11 +943,13 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   u32* heavy_count = ctx->d_heavy;
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
-  // Phase events (bn256_last_timing) are recorded from 2^17 sorted entries on: an event between two
-  // kernels costs 6-8 us of stream time (rocprofv3 kernel trace, 64 points: kernels that follow one another
-  // directly start with no gap), seven of them a third of a small call.  BN256_PHASE_TIMING=1 forces them.
-  static const bool force_timing = getenv("BN256_PHASE_TIMING") && atoi(getenv("BN256_PHASE_TIMING")) > 0;
-  const bool timed = force_timing || nchunks > 1 || (unsigned long long)nmax * W >= (1ull << 17);
+  // Phase events (bn256_last_timing) are recorded only on request (bn256_ctx_set_phase_timing, or
+  // BN256_PHASE_TIMING=1 in the environment): an event between two kernels costs 6-8 us of stream time
+  // (rocprofv3 kernel trace, 64 points: kernels that follow one another directly start with no gap) --
+  // seven of them are a third of a small call and 1-2.5 % of a 2^20-point one (tools/event_cost.py) -- and a
+  // call of several passes has to wait for every pass to read them.
+  static const int env_timing = getenv("BN256_PHASE_TIMING") ? atoi(getenv("BN256_PHASE_TIMING")) : -1;
+  const bool timed = env_timing >= 0 ? env_timing > 0 : ctx->phase_timing != 0;
   pend->timed = timed;
 #define MSM_MARK(i) do { if (timed) HIPCHK(hipEventRecord(ctx->ev[i], s)); } while (0)
   // The split-sort kernels (groups larger than pass B's LDS capacity: skewed scalars) are three
@@ -1096,7 +1107,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     if ((rc = upload_pass(cj + 1))) return rc;  // the next pass's scalars cross PCIe under this pass's kernels
     // per-pass phase times (the last pass is read after the reduction); not with host scalars: the wait
     // would keep the next pass's kernels from being enqueued under this pass
-    if (ch + 1 < nchunks && !hold_stream && !t.host_sc) {
+    if (timed && ch + 1 < nchunks && !hold_stream && !t.host_sc) {
       HIPCHK(hipStreamSynchronize(s));
       for (int i = 0; i < 5; i++) {
         float ms;

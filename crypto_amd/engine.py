@@ -129,6 +129,10 @@ class Engine:
     def set_tuning(self, window_bits: int = 0, chunk: int = 0) -> None:
         self._chk(self.lib.bn256_ctx_set_tuning(self.ctx, window_bits, chunk))
 
+    def set_phase_timing(self, on: bool = True) -> None:
+        """Per-phase HIP events for last_timing() (off by default: they cost stream time)."""
+        self._chk(self.lib.bn256_ctx_set_phase_timing(self.ctx, 1 if on else 0))
+
     def last_timing(self) -> list[float]:
         arr = (C.c_float * 7)()
         k = self.lib.bn256_last_timing(self.ctx, arr, 7)

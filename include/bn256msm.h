@@ -274,9 +274,11 @@ int bn256_ctx_set_tuning(bn256_ctx* ctx, int window_bits, int chunk);
 
 /* Per-phase GPU time (ms, HIP events on the context stream) of the last bn256_msm* call:
  * [0] recode+count  [1] scan  [2] scatter  [3] bucket accumulation  [4] partial fix-up
- * [5] bucket reduction  [6] total device time.  Returns the number of values written.  Calls of fewer than
- * 2^17 (points x windows) are not instrumented and report zeros -- the events would be a third of such a
- * call's device time -- unless the environment has BN256_PHASE_TIMING=1. */
+ * [5] bucket reduction  [6] total device time.  Returns the number of values written.  Zeros unless the
+ * instrumentation was switched on with bn256_ctx_set_phase_timing(ctx, 1) (or BN256_PHASE_TIMING=1 in the
+ * environment; =0 forces it off): the seven event records cost 6-8 us of stream time each -- a third of a
+ * 64-point call, 1-2.5 % of a 2^20-point one -- and make a call of several passes wait for each pass. */
+int bn256_ctx_set_phase_timing(bn256_ctx* ctx, int on);
 int bn256_last_timing(bn256_ctx* ctx, float* ms, int cap);
 
 /* Field-arithmetic self test on the device (fe_mul inline-asm path against its portable

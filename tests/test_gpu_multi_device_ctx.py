@@ -55,11 +55,15 @@ def test_2_20_closed_form_and_single_device_bytes(multi2, eng, orc):
         assert multi2.msm_dev(h, v.device_ptr(), n) == want           # device pointer
         assert multi2.msm_fr(h, 0, 1, n, v) == want                    # resident Fr vector
         sraw = b"".join(x.to_bytes(32, "big") for x in v.download(0, 70000))
+        multi2.set_phase_timing(True)
         part = multi2.msm(h, sraw, off=0, n=70000)                     # host scalars
         assert part == eng.msm_dev(h1, v.device_ptr(), 70000)
         assert eng.msm_dev(h1, v.device_ptr(), n) == want
         t = multi2.last_timing()
         assert len(t) == 7 and t[3] > 0
+        multi2.set_phase_timing(False)
+        multi2.msm(h, sraw, off=0, n=70000)
+        assert multi2.last_timing() == [0.0] * 7                       # off by default: no events, no times
     finally:
         h.free()
         h1.free()

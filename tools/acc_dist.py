@@ -2,6 +2,7 @@ import os, sys, time, statistics
 sys.path.insert(0, os.getcwd())
 import torch, crypto_amd
 eng = crypto_amd.Engine(0)
+eng.set_phase_timing(True)  # last_timing() below
 n = 1 << 20
 b = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
 s = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")

@@ -2,6 +2,7 @@ import sys, os, time, statistics
 sys.path.insert(0, os.getcwd())
 import crypto_amd
 eng = crypto_amd.Engine(0)
+eng.set_phase_timing(True)  # last_timing() below
 N = (1 << 21) + 64
 H = eng.random_bases(0xB9901, N, flags=crypto_amd.PRECOMPUTE)
 v = eng.fr_random(0x21, N)

@@ -23,6 +23,7 @@ args = ap.parse_args()
 n = 1 << args.log2n
 
 eng = crypto_amd.Engine(0)
+eng.set_phase_timing(True)  # last_timing() below
 bases = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
 dscal = torch.empty(n * 32, dtype=torch.uint8, device="cuda:0")
 eng.random_scalars_into(0x5EED0002, n, dscal.data_ptr())

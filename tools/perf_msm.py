@@ -17,6 +17,7 @@ ap.add_argument("--no-precompute", action="store_true")
 args = ap.parse_args()
 
 eng = crypto_amd.Engine(0)
+eng.set_phase_timing(True)  # last_timing() below
 n = 1 << args.log2n
 if os.environ.get("PERF_PREALLOC"):
     dummy = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)

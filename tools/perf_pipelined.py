@@ -26,6 +26,7 @@ torch.cuda.set_device(0)
 ctxs = []
 for t in range(a.threads):
     eng = crypto_amd.Engine(0)
+    eng.set_phase_timing(True)  # last_timing() below
     bases = eng.random_bases(0x5EED0001, n, flags=crypto_amd.PRECOMPUTE)
     sc = torch.empty(n * 32, dtype=torch.uint8, device=dev)
     eng.random_scalars_into(0x5EED0002, n, sc.data_ptr())

@@ -8,6 +8,7 @@ if "setdev" in V:
     torch.cuda.set_device(0)
 import crypto_amd
 eng = crypto_amd.Engine(0)
+eng.set_phase_timing(True)  # last_timing() below
 n = 1 << 20
 if "basesfirst" in V:
     bases = eng.random_bases(0x5EED0001, n, flags=1)
