@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
 // more than FIX_LANE_CAP partial sums (skewed scalars) go to the medium queue, which k_heavy's quads work
 // off as serial chains, those above FIX_CAP to the heavy queue.  Buckets without entries were set to
 // infinity by the sort.
-#define FIX_LANE_CAP 3u
+#define FIX_LANE_CAP 4u
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_fix_boundary(const u32* __restrict__ offsets, u32 nbt, u32 K, const u32* __restrict__ lastb,
                xyzz_mem* __restrict__ buckets, const xyzz_mem* __restrict__ partials, u32* __restrict__ heavy_count,

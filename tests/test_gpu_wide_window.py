@@ -105,7 +105,7 @@ def test_skewed_scalars_take_the_split_path_and_recover(wide, orc, table):
 
 
 def test_repeated_scalars_chains_and_heavy_queue(wide, orc, table):
-    """k_fix_boundary joins up to three partial sums of a bucket per lane; buckets that span 4..32 chunks go
+    """k_fix_boundary joins up to four partial sums of a bucket per lane; buckets that span 5..32 chunks go
     to the medium queue (serial chains by k_heavy's quads), longer ones to the heavy queue.  Scalars drawn
     from d distinct values put 13 n / (13 d) entries into each of <= 13 d buckets: 1-2, ~11, ~55 and ~440
     chunks of 16 entries."""
