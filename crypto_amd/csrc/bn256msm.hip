@@ -1372,14 +1372,17 @@ static int multi_enqueue(bn256_ctx* ctx, int k, const bn256_bases* const* b, con
     msm_src srcs[16];
     int m = 0;
     size_t pos = 0;
+    // the scalars are uploaded pass by pass beside the kernels (msm_src::host_sc).  The buffers must stay
+    // valid until the pipeline has run: a blocking caller waits in msm_finish, a lane's job owns copies.
     for (int i = 0; i < k; i++) {
       if (!n[i]) continue;
-      HIPCHK(hipMemcpyAsync(sc + pos * 32, scalars_be[i], n[i] * 32, hipMemcpyHostToDevice, ctx->stream));
-      srcs[m++] = msm_src{b[i], off[i], stride ? stride[i] : 1, n[i], sc + pos * 32, 1};
+      srcs[m] = msm_src{b[i], off[i], stride ? stride[i] : 1, n[i], sc + pos * 32, 1};
+      srcs[m++].host_sc = scalars_be[i];
       pos += n[i];
     }
-    if (hold_stream) HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's buffers are not ours after return
-    return msm_enqueue_srcs(ctx, srcs, m, hold_stream, pend);
+    rc = msm_enqueue_srcs(ctx, srcs, m, hold_stream, pend);
+    if (rc && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    return rc;
   }
   if (big_table || total_n >= (1ull << 31)) {
     *single = false;
