@@ -21,7 +21,10 @@ class BN256Error(RuntimeError):
         self.code = code
 
 
-def scalars_to_bytes(scalars: Iterable[int]) -> bytes:
+def scalars_to_bytes(scalars) -> bytes:
+    """32-byte big-endian strings (scalarTo32Byte, go/bp/util.go:209-220); bytes pass through."""
+    if isinstance(scalars, (bytes, bytearray)):
+        return bytes(scalars)
     return b"".join(int(s).to_bytes(32, "big") for s in scalars)
 
 
