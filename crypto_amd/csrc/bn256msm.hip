@@ -484,9 +484,13 @@ static void normalize_into(bn256_ctx* ctx, const xyzz_mem* in, aff_mem* out, siz
 // With wide windows the top window is much narrower than the others (c = 20: 13 windows, the top one
 // holds bits 240..254 of a scalar below n/2, values <= 18395 of 2^19): its 2^20 digits per 2^20 points
 // would all land in the first 3.5 % of the buckets and make the sort's first groups three times as
-// large as the rest.  The top table level is therefore stored as (1 / s) * 2^(c (W-1)) * P and the top
-// digit multiplied by s = floor(2^(c-1) / 18395): the same sum, with the top window's entries spread
-// over the whole bucket range.  s = 1 (nothing changes) for every other window width.
+// large as the rest.  The top table level is therefore stored as (1 / s_i) * 2^(c (W-1)) * P_i and the top
+// digit multiplied by s_i = s - (i & 3), s = floor(2^(c-1) / 18395) = 28: the same sum, with the top
+// window's entries spread over the whole bucket range.  One s for every point would put them on every
+// 28th bucket only, 57 extra entries each: buckets three times the average, each across two or three
+// chunk boundaries of the accumulation, so that every wave of k_fix_boundary ran a chain of two additions
+// where most lanes have one.  Four scales hit four times as many buckets with a quarter each.
+// s = 1 (nothing changes) for every other window width.
 static u32 top_scale_for(int c) {
   if (c != 20) return 1;
   const int W = windows_for(c);
@@ -537,12 +541,15 @@ static int bases_precompute(bn256_ctx* ctx, bn256_bases* b) {
     normalize_into(ctx, xs, b->d + (size_t)l * b->n, b->n);
   }
   b->top_scale = top_scale_for(b->c);
-  if (b->top_scale > 1) {  // top level *= 1 / top_scale: one scalar for every point, in place
-    uint8_t inv_be[32];
-    static const uint8_t zero[32] = {0};
-    small_inverse_mod_n(inv_be, b->top_scale);
+  if (b->top_scale > 1) {  // top level of point i *= 1 / (top_scale - i mod TOP_SCALES), in place (top_scale_of, kernels.cuh)
+    uint8_t inv_be[TOP_SCALES * 32];
+    for (u32 r = 0; r < TOP_SCALES; r++) small_inverse_mod_n(inv_be + 32 * r, b->top_scale - r);
     aff_mem* top = b->d + (size_t)(b->levels - 1) * b->n;
-    if ((rc = fold_points(ctx, top, top, 1u, inv_be, zero, (u32)b->n, 0u, &xs))) return rc;
+    if ((rc = ws_reserve(ctx, WS_SCALARS, sizeof(inv_be)))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], inv_be, sizeof(inv_be), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // inv_be is on this stack
+    hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(b->n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)top,
+                       (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)b->n, TOP_SCALES, 0u);
     normalize_into(ctx, xs, top, b->n);
   }
   HIPCHK(hipGetLastError());
@@ -1026,10 +1033,10 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
       if (wide)
         hipLaunchKernelGGL((k_part<20, true>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W, (u32)sc_stride,
-                           G2, LB2, ibits, key_stride, top_scale, gtotal, loc, rank);
+                           G2, LB2, ibits, key_stride, top_scale, (u32)off_ch, (u32)stride, gtotal, loc, rank);
       else
         hipLaunchKernelGGL((k_part<16, false>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W,
-                           (u32)sc_stride, G2, LB2, ibits, key_stride, top_scale, gtotal, loc, rank);
+                           (u32)sc_stride, G2, LB2, ibits, key_stride, top_scale, (u32)off_ch, (u32)stride, gtotal, loc, rank);
       MSM_MARK(1);
       MSM_MARK(2);
       const u32 init_inf = ch == 0 ? 1u : 0u;  // buckets without entries: infinity on the call's first pass
@@ -1125,9 +1132,17 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   } else {
   for (u32 l = 0; l < q; l++) {
     size_t threads = (size_t)nsets * (l + 1) * ((nb >> l) >> 1);
+    const size_t threads_next = l + 1 < q ? (size_t)nsets * (l + 2) * ((nb >> (l + 1)) >> 1) : 0;
+    if (threads_next >= ((size_t)1 << 17)) {  // this level and the next are both throughput work: one lane per four inputs
+      const size_t lanes = (size_t)nsets * (l + 1) * ((nb >> l) >> 2);
+      hipLaunchKernelGGL(k_fold_lane2, dim3(nblocks(std::min<size_t>(lanes, 131072), 256)), dim3(256), 0, s, sum_buckets,
+                         nsets, nb, l);
+      l++;
+      continue;
+    }
     if (threads >= ((size_t)1 << 17)) {  // a level of that many independent additions is throughput work: lane per addition
-      // whole waves per SIMD (1024 SIMDs x 64 lanes): three while the level fits them, else two and a grid-stride loop
-      const size_t launch = threads <= 196608 ? threads : 131072;
+      // at most one full round of four waves per SIMD (1024 SIMDs x 64 lanes; the kernel is held to 128 VGPRs)
+      const size_t launch = std::min<size_t>(threads, 262144);
       hipLaunchKernelGGL(k_fold_lane, dim3(nblocks(launch, 256)), dim3(256), 0, s, sum_buckets, nsets, nb, l);
     } else
       hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, sum_buckets, nsets, nb, l);

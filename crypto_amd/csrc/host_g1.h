@@ -124,7 +124,7 @@ inline void to_raw(uint64_t w[4], const Fp& a) {
   Fp t = mul(a, one);
   memcpy(w, t.l, 32);
 }
-inline Fp inv(const Fp& a) {  // a^(p-2)
+inline Fp inv_fermat(const Fp& a) {  // a^(p-2): 16 us here; kept as the check of inv() in tests
   uint64_t e[4] = {kP[0] - 2, kP[1], kP[2], kP[3]};
   Fp acc = kOne;
   for (int i = 255; i >= 0; i--) {
@@ -132,6 +132,66 @@ inline Fp inv(const Fp& a) {  // a^(p-2)
     if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, a);
   }
   return acc;
+}
+// x / 2 mod p for x in [0, p)
+inline void halve_mod_p(uint64_t x[4]) {
+  uint64_t top = 0;
+  if (x[0] & 1) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (u128)x[i] + kP[i];
+      x[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    top = (uint64_t)c;
+  }
+  for (int i = 0; i < 3; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 63);
+  x[3] = (x[3] >> 1) | (top << 63);
+}
+inline bool raw_geq(const uint64_t a[4], const uint64_t b[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+inline void raw_sub(uint64_t a[4], const uint64_t b[4]) {  // a -= b, a >= b
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a[i] - b[i] - br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+// 1 / a by the binary extended Euclidean algorithm for an odd modulus (the invariants u = x1 A, v = x2 A
+// mod p with A = a R the representation itself): ~1.5 us against 16 us for a^(p-2), and the one inversion
+// of marshal() is on every call's critical path.  inv(0) = 0, as a^(p-2) gives.
+inline Fp inv(const Fp& a) {
+  if (is_zero(a)) return a;
+  uint64_t u[4] = {a.l[0], a.l[1], a.l[2], a.l[3]}, v[4] = {kP[0], kP[1], kP[2], kP[3]};
+  Fp x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+  auto is_one = [](const uint64_t w[4]) { return w[0] == 1 && (w[1] | w[2] | w[3]) == 0; };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) {
+      for (int i = 0; i < 3; i++) u[i] = (u[i] >> 1) | (u[i + 1] << 63);
+      u[3] >>= 1;
+      halve_mod_p(x1.l);
+    }
+    while (!(v[0] & 1)) {
+      for (int i = 0; i < 3; i++) v[i] = (v[i] >> 1) | (v[i + 1] << 63);
+      v[3] >>= 1;
+      halve_mod_p(x2.l);
+    }
+    if (raw_geq(u, v)) {
+      raw_sub(u, v);
+      x1 = sub(x1, x2);
+    } else {
+      raw_sub(v, u);
+      x2 = sub(x2, x1);
+    }
+  }
+  // x = A^-1 = a^-1 R^-1 as a plain integer; times R^3 / R gives a^-1 R
+  static const Fp kR3 = mul(kR2, kR2);
+  return mul(is_one(u) ? x1 : x2, kR3);
 }
 
 struct Pt {  // XYZZ; infinity <=> zz == 0

@@ -215,6 +215,13 @@ __device__ __forceinline__ u32 recode_carry_into(const u32 k[8], u32 w, u32 c) {
   return 0u;
 }
 
+// Wide-window tables (bases_precompute): the top table level of point i holds (1 / s_i) 2^(c (W-1)) P_i with
+// s_i = top_scale - (i mod TOP_SCALES), and the point's top digit is multiplied by s_i.  top_scale = 1: nothing of this.
+#define TOP_SCALES 8u
+__device__ __forceinline__ u32 top_scale_of(u32 top_scale, u32 table_index) {
+  return top_scale > 1u ? top_scale - (table_index & (TOP_SCALES - 1u)) : top_scale;
+}
+
 template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 nb,
                                                     u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride, u32 tile_len,
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
     for (u32 w = w_lo; w < w_hi; w++) {
       u32 mag, sign;
       recode_digit(k, neg, w, c, carry, mag, sign);
-      if (w == W - 1) mag *= top_scale;  // see bases_precompute: the top table level is divided by top_scale
+      if (w == W - 1) mag *= top_scale_of(top_scale, base_off + i * pt_stride);
       if (mag == 0) continue;
       if (!SCATTER) {
         atomicAdd(&lds[mag - 1], 1u);
@@ -325,7 +332,7 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32 B, u32* tmp) {
 template <int C, bool TL>
 __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 W, u32 sc_stride,
                                                u32 G, u32 LB, u32 ibits, u32 key_stride, u32 top_scale,
-                                               u32* __restrict__ gtotal,
+                                               u32 base_off, u32 pt_stride, u32* __restrict__ gtotal,
                                                u32* __restrict__ loc, u32* __restrict__ rec) {
   extern __shared__ u32 lds[];  // cnt[G], cur[G], then per-wave histograms [16][G] aliased by stage[TCAP]
   constexpr u32 c = C;
@@ -357,7 +364,7 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
       if (w < 255 / C + 1 && i < hi && w < W) {
         u32 mag, sign;
         recode_digit(k, neg, w, c, carry, mag, sign);
-        if (w == W - 1) mag *= top_scale;
+        if (w == W - 1) mag *= top_scale_of(top_scale, base_off + i * pt_stride);
         if (mag != 0) {
           u32 key = w * key_stride + mag - 1, grp = key >> LB;
           u32 wfield = key_stride ? 0u : (w << (TL ? 11u : ibits));
@@ -757,7 +764,7 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scal
   for (u32 w = 0; w < W; w++) {
     u32 mag, sign;
     recode_digit(k, neg, w, c, carry, mag, sign);
-    if (w == W - 1) mag *= top_scale;
+    if (w == W - 1) mag *= top_scale_of(top_scale, base_off + i * pt_stride);
     if (mag == 0) continue;
     u32 key = (precomp ? 0u : w * nb) + mag - 1u;
     if (!SCATTER) {
@@ -1171,13 +1178,14 @@ __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32
 // there.  The host picks this kernel for levels of >= 2^17 additions.  It is issue-bound like the
 // accumulation (~3300 instructions per general addition; moving the 144-byte records through LDS with
 // coalesced 16-byte accesses instead of nine strided loads per lane changed nothing: measured).
-__global__ void __launch_bounds__(256) k_fold_lane(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_fold_lane(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
   u32 half = (nb >> level) >> 1;
   u32 rows = level + 1;
   u64 per_set = (u64)rows * half;
   const u64 total = per_set * nsets, step = (u64)gridDim.x * blockDim.x;
-  // grid-stride: the host launches a whole number of waves per SIMD (161 VGPRs: three fit) so that a level
-  // never ends in a sparsely filled extra round
+  // grid-stride: the host launches at most one full round of four waves per SIMD (128 VGPRs by the attribute:
+  // 0.225 -> 0.221 ms for the reduction against 134 VGPRs, three waves and two rounds)
   for (u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += step) {
     u32 set = (u32)(tid / per_set);
     u32 rem = (u32)(tid % per_set);
@@ -1189,6 +1197,40 @@ __global__ void __launch_bounds__(256) k_fold_lane(xyzz_mem* __restrict__ bucket
     xyzz_load(b, p + half);
     xyzz_add(r, a, b);
     xyzz_store(p, r);
+  }
+}
+
+// Levels l and l + 1 in one launch, one lane per FOUR inputs of a row: with h = half the row width of level
+// l and q = h / 2, lane i of a row at `base` reads a = B[i], b = B[i+q], c = B[i+h], d = B[i+h+q] and leaves
+// B[i] = (a + c) + (b + d).  In the main row the upper halves of both levels live on as rows of their own:
+// B[i+q] = b + d (level l + 1's upper half) and B[i+h] = c + d (level l's upper half, folded once).
+// Against two k_fold_lane launches: 4 loads + 3 stores per 4 additions instead of 8 + 4 (1 store per 3
+// additions in the other rows), and a lane's next operands load while it computes -- the one-addition
+// kernel's waves all load, then all compute, then all store.
+__global__ void __launch_bounds__(256) k_fold_lane2(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  const u32 h = (nb >> level) >> 1, q = h >> 1;
+  const u32 rows = level + 1;
+  const u64 per_set = (u64)rows * q;
+  const u64 total = per_set * nsets, step = (u64)gridDim.x * blockDim.x;
+  for (u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += step) {
+    const u32 set = (u32)(tid / per_set);
+    const u32 rem = (u32)(tid % per_set);
+    const u32 row = rem / q, i = rem % q;
+    xyzz_mem* p = buckets + (size_t)set * nb + (row == 0 ? 0u : (nb >> row)) + i;
+    xyzz c, d, r, a;
+    xyzz_load(c, p + h);
+    xyzz_load(d, p + h + q);
+    if (row == 0) {
+      xyzz_add(r, c, d);
+      xyzz_store(p + h, r);
+    }
+    xyzz_load(a, p);
+    xyzz_add(r, a, c);      // a + c
+    xyzz_load(a, p + q);
+    xyzz_add(c, a, d);      // b + d
+    if (row == 0) xyzz_store(p + q, c);
+    xyzz_add(d, r, c);
+    xyzz_store(p, d);
   }
 }
 
@@ -1413,7 +1455,7 @@ __device__ __forceinline__ void g1_scalar_mul(xyzz& acc, const fe& x, const fe& 
   }
 }
 
-// out[i] = s_i * in[i]   (broadcast_scalar: s_0 for all; broadcast_point: in[0] for all)
+// out[i] = s_i * in[i]   (broadcast_scalar = p > 0: s_(i mod p), so 1 is s_0 for all; broadcast_point: in[0] for all)
 __global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ in, const uint8_t* __restrict__ scalars_be,
                                                     xyzz_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
                                                     u32 broadcast_point) {
@@ -1424,7 +1466,7 @@ __global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ 
   xyzz_set_inf(acc);
   if (aff_load(x, y, &in[broadcast_point ? 0 : i], false)) {
     u32 k[8];
-    scalar_load_be(k, scalars_be + (broadcast_scalar ? 0 : (size_t)i * 32));
+    scalar_load_be(k, scalars_be + (size_t)(broadcast_scalar ? i % broadcast_scalar : i) * 32);
     g1_scalar_mul(acc, x, y, k);
   }
   xyzz_store(&out[i], acc);

@@ -1,8 +1,10 @@
 #!/bin/bash
 # A/B of two builds of the library on ONE box through bench.py's timed loop (three calls in flight) and its
-# blocking calls:  bash tools/ab_bench.sh   (crypto_amd/libbn256msm_base.so = the build to compare against)
+# blocking calls:  bash tools/ab_bench.sh   (crypto_amd/libbn256msm_base.so = the build to compare against;
+# environment switches given as arguments, e.g. BN256_FOLD2=0, apply to both)
 export TMPDIR=/tmp
 O=gpurun_out
+for a in "$@"; do export "$a"; done
 for rep in 1 2 3; do
   for v in base new; do
     if [ $v = base ]; then export BN256MSM_LIB=$PWD/crypto_amd/libbn256msm_base.so; else unset BN256MSM_LIB; fi
