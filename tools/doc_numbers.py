@@ -71,7 +71,7 @@ L.append("")
 L.append("| kernel (rocprofv3 kernel trace, `--depth 1`: one call on the chip) | launches per call | average µs |")
 L.append("|---|---|---|")
 calls = d1.get("k_accumulate<true>", (1, 0))[0]
-for k in ("k_part<20, true>", "k_group_sort_tl", "k_accumulate<true>", "k_fix_boundary", "k_heavy", "k_fold_lane", "k_fold", "k_pack_results"):
+for k in ("k_part<20, true>", "k_group_sort_tl", "k_accumulate<true>", "k_fix_boundary", "k_heavy", "k_fold_lane2", "k_fold_lane", "k_fold", "k_pack_results"):
     if k in d1:
         L.append(f"| `{k}` | {d1[k][0] / calls:.0f} | {d1[k][1]:.1f} |")
 block = "\n".join(L)
