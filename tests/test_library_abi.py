@@ -69,6 +69,21 @@ def test_host_g1_sum_matches_oracle():
     assert lib.bn256_g1_sum(ref.P.to_bytes(32, "big") + bytes(32), 1, out) == -3
 
 
+def test_host_normalisation_over_many_points():
+    """Every result leaves the library through hostg1::marshal, whose one inversion is a binary extended
+    Euclid (host_g1.h: inv): 150 random two-point sums against the oracle's affine bytes."""
+    import random
+    from crypto_amd import _lib
+    lib = _lib.load()
+    rng = random.Random(0x1A7)
+    out = C.create_string_buffer(64)
+    for _ in range(150):
+        k1, k2 = rng.randrange(1, ref.N), rng.randrange(1, ref.N)
+        pts = ref.marshal(ref.mul(k1, ref.G0)) + ref.marshal(ref.mul(k2, ref.G0))
+        assert lib.bn256_g1_sum(pts, 2, out) == 0
+        assert out.raw == ref.marshal(ref.mul((k1 + k2) % ref.N, ref.G0))
+
+
 def test_glv_split_host_arithmetic():
     """bn256_glv_split (pure host code behind the generator folds): k = k1 + k2*lambda mod n with
     |k1|, |k2| < 2^129, and lambda*(x, y) = (beta*x, y) on the oracle's curve."""
