@@ -14,9 +14,12 @@ A "step" is one complete MSM: every rank runs the device pipeline on its contigu
 points (bases resident in HBM with their fixed-base table, scalars resident in HBM when the timed
 region starts), the 64-byte partial sums are exchanged with one RCCL all_gather, and every rank adds
 them on the host.  value = total points / second.  Steps are issued through bn256_msm_submit /
-bn256_msm_wait with --depth (default 3) calls in flight, the way a prover issues its independent
+bn256_msm_wait with --depth (default 4) calls in flight, the way a prover issues its independent
 commitments (A and S, L and R): step i+1 is enqueued before step i's result is collected, and all K
-results are collected inside the timed region.
+results are collected inside the timed region.  Every call in flight runs on a HIP stream of its own; the
+process asks for 8 hardware queues (GPU_MAX_HW_QUEUES, raised below if the environment's value is lower) so
+that no two of them share one -- with HIP's default of 4, two of four lanes are served in order by one queue
+and their calls do not overlap (tools/probe/stream_probe.hip).
 
   default            weak scaling: 2^log2n points per GPU (2^20 = BASELINE.json configs[2] per GPU)
   --total-log2n T    strong scaling: 2^T points in all, rank r takes the r-th contiguous slice
@@ -39,6 +42,10 @@ import statistics
 import sys
 import time
 
+# before anything loads the HIP runtime (see above); BENCH_HW_QUEUES=0 leaves the environment's value alone
+if os.environ.get("BENCH_HW_QUEUES", "8") != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = str(max(int(os.environ.get("GPU_MAX_HW_QUEUES") or 4),
+                                              int(os.environ.get("BENCH_HW_QUEUES", "8"))))
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -61,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip single_call / pcie / 2^24 / bulletproofs-like legs")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--depth", type=int, default=3, choices=[1, 2, 3, 4], help="MSM calls in flight per GPU")
+    ap.add_argument("--depth", type=int, default=4, choices=[1, 2, 3, 4], help="MSM calls in flight per GPU")
     return ap.parse_args(argv)
 
 
@@ -264,7 +271,7 @@ def worker(args) -> int:
                 "rank0_slice": [wl.first, wl.n],
                 "fixed_base_table": not args.no_precompute,
                 "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials, host sum",
-                "calls_in_flight": args.depth,
+                "calls_in_flight": args.depth, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES") or 4),
                 "setup_seconds_bases": wl.setup_s,
                 "result_xy": result.hex(),
             },

@@ -125,7 +125,7 @@ def test_run_pipelined_schedule():
             return [self.out.pop(k)]
 
     g0 = (1).to_bytes(32, "big") + (0x8fb501e34aa387f9aa6fecb86184dc21ee5b88d120b5b59e185cac6c5e089667 - 2).to_bytes(32, "big")
-    for depth in (1, 2, 3):
+    for depth in (1, 2, 3, 4):
         for steps in (0, 1, 2, 3, 7):
             for with_ex in (False, True):
                 log, inflight, max_inflight = [], [], [0]
