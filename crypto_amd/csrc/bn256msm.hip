@@ -1043,8 +1043,8 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       u32* oversized = d_flags + (split ? 1 : 0);
       if (wide)
         hipLaunchKernelGGL(k_group_sort_tl, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
-                           (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, (u32)off_ch, (u32)stride, (u32)b->n, offsets, sval,
-                           buckets, init_inf, oversized);
+                           (const u32*)gtotal, nt2, (u32)((n_ch + SORT2_TILE - 1) / SORT2_TILE), (u32)nbt, LB2, NH2, (u32)off_ch,
+                           (u32)stride, (u32)b->n, offsets, sval, buckets, init_inf, oversized);
       else
         hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
                            (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets,
