@@ -873,9 +873,11 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     return (t + SORT2_S - 1) / SORT2_S * SORT2_S;
   };
   const u32 tiles2_max = tiles2_for(nmax);
-  // a pass uses it only with >= 2^18 points with a table, 2^19 without: below, the fixed costs of the
-  // 2^9..2^10 groups dominate
-  const size_t two_min = (size_t)1 << (precomp ? 18 : 19);
+  // a pass uses it from 2^15 points on with a table and from 2^17 (where 16-bit windows start) without: swept with
+  // BN256_TWO_MIN_LOG2 -- 50 000 points over a table 0.323 -> 0.308 ms, 2^17 0.417 -> 0.383, 2^18 - 1 0.554 ->
+  // 0.485; table-less 2^17 0.715 -> 0.622, 2^19 - 1 1.179 -> 1.001 (the thresholds used to be 2^18 and 2^19)
+  static const int two_min_env = getenv("BN256_TWO_MIN_LOG2") ? atoi(getenv("BN256_TWO_MIN_LOG2")) : 0;
+  const size_t two_min = (size_t)1 << (two_min_env ? two_min_env : precomp ? 15 : 17);
   const bool two_pass =
       wide ? (!ctx->sort1 && G2 == 512 && tiles2_max <= 1024 && nmax >= two_min && nmax <= ((size_t)1 << 20) + ((size_t)1 << 17) &&
               entries_max <= (unsigned long long)G2 * 32768)

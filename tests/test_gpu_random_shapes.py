@@ -133,3 +133,30 @@ def test_random_calls_on_a_multi_device_context(orc, seed):
             h.free()
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("table", [True, False])
+def test_sizes_around_the_two_pass_sort_thresholds(orc, table):
+    """The two-pass LDS sort takes over from 2^15 points with a table and from 2^17 without
+    (msm_enqueue_srcs, two_min): sizes on both sides of the switch, uniform and skewed scalars (the aL / aR
+    distribution puts nearly every record into one group: the oversized flag and the repeat with the split
+    kernels at the smallest sizes the path now sees)."""
+    rng = random.Random(0x2BA5 + table)
+    e = crypto_amd.Engine(0)
+    try:
+        edge = 1 << (15 if table else 17)
+        size = edge + 4097
+        seed_b = 0x2BA50 + table
+        h = e.random_bases(seed_b, size, flags=crypto_amd.PRECOMPUTE if table else 0)
+        ks = orc.synth_base_scalars(seed_b, size)
+        for n in (edge - 1, edge, edge + 1, edge + 2049, edge + 4097):
+            for dist in ("uniform", "bits", "few"):
+                a = _scalars(rng, dist, n)
+                v = e.fr_upload(_be(x % N for x in a))
+                got = e.msm_dev(h, v.device_ptr(), n)
+                v.free()
+                want = orc.fr_dot(_be(x % N for x in a), ks[:32 * n])
+                assert got == orc.g0_mul(want), f"table {table} n {n} {dist}"
+        h.free()
+    finally:
+        e.close()
