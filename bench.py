@@ -12,8 +12,8 @@ bench.py --gpus N` the ranks are the launcher's and this script is a rank at onc
 
 A "step" is one complete MSM: every rank runs the device pipeline on its contiguous slice of the
 points (bases resident in HBM with their fixed-base table, scalars resident in HBM when the timed
-region starts), the 64-byte partial sums are exchanged with one RCCL all_gather, and every rank adds
-them on the host.  value = total points / second.  Steps are issued through bn256_msm_submit /
+region starts), the 64-byte partial sums are exchanged with an RCCL all_gather (one per --depth finished
+steps: their partial sums travel together), and every rank adds them on the host.  value = total points / second.  Steps are issued through bn256_msm_submit /
 bn256_msm_wait with --depth (default 4) calls in flight, the way a prover issues its independent
 commitments (A and S, L and R): step i+1 is enqueued before step i's result is collected, and all K
 results are collected inside the timed region.  Every call in flight runs on a HIP stream of its own; the
@@ -132,7 +132,9 @@ def worker(args) -> int:
     eng = crypto_amd.Engine(local_rank)
     eng.set_tuning(args.window_bits, args.chunk)
     flags = 0 if args.no_precompute else crypto_amd.PRECOMPUTE
-    ex = sharding.AsyncExchange(world, dev) if use_dist else None
+    # one all_gather per `depth` finished steps (sharding.AsyncExchange: an exchange costs the loop ~80 us of host
+    # time; rehearsed with one rank, 64 steps: 790 Mpts/s with one exchange per step, 865 with one per four, 887 without)
+    ex = sharding.AsyncExchange(world, dev, batch=args.depth) if use_dist else None
     host_us = [0.0] * 3  # host time in submit / wait / exchange (start, finish of an older one, sum)
 
     def sync():
@@ -270,7 +272,7 @@ def worker(args) -> int:
                 "points_per_gpu": n,
                 "rank0_slice": [wl.first, wl.n],
                 "fixed_base_table": not args.no_precompute,
-                "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials, host sum",
+                "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials ({args.depth} steps' worth per call), host sum",
                 "calls_in_flight": args.depth, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES") or 4),
                 "setup_seconds_bases": wl.setup_s,
                 "result_xy": result.hex(),

@@ -19,16 +19,16 @@ class _Exchange:
     """Persistent buffers for the per-step exchange (allocated once per device and world size:
     the timed loop of bench.py must not allocate)."""
 
-    def __init__(self, world: int, device):
+    def __init__(self, world: int, device, batch: int = 1):
         import torch
-        self.world, self.device = world, device
+        self.world, self.device, self.batch = world, device, batch
         on_gpu = device is not None and torch.device(device).type == "cuda"
-        self.h_in = torch.empty(64, dtype=torch.uint8)
-        self.h_out = torch.empty(64 * world, dtype=torch.uint8)
+        self.h_in = torch.zeros(64 * batch, dtype=torch.uint8)
+        self.h_out = torch.zeros(64 * batch * world, dtype=torch.uint8)
         if on_gpu:
             self.h_in, self.h_out = self.h_in.pin_memory(), self.h_out.pin_memory()
-            self.d_in = torch.empty(64, dtype=torch.uint8, device=device)
-            self.d_out = torch.empty(64 * world, dtype=torch.uint8, device=device)
+            self.d_in = torch.empty(64 * batch, dtype=torch.uint8, device=device)
+            self.d_out = torch.empty(64 * batch * world, dtype=torch.uint8, device=device)
         else:
             self.d_in, self.d_out = self.h_in, self.h_out
         self.on_gpu = on_gpu
@@ -44,7 +44,7 @@ class _Exchange:
             self.h_out.copy_(self.d_out, non_blocking=True)
             torch.cuda.current_stream(self.device).synchronize()
         raw = self.h_out.numpy().tobytes()
-        return [raw[64 * i:64 * i + 64] for i in range(self.world)]
+        return [raw[64 * self.batch * i:64 * self.batch * i + 64] for i in range(self.world)]
 
 
 class AsyncExchange:
@@ -53,30 +53,43 @@ class AsyncExchange:
     kernel issued now is scheduled only when that kernel drains, and a host that waited for it could
     not enqueue the next MSM in time.  start() enqueues copy-in, all_gather and copy-out on a side
     stream and returns a ticket; finish() waits for that ticket's event -- one or two steps later,
-    when it has long completed.  `slots` exchanges may be outstanding."""
+    when it has long completed.  `slots` exchanges may be outstanding.
 
-    def __init__(self, world: int, device, slots: int = 4):
+    `batch` > 1: one all_gather carries the partial sums of up to `batch` finished calls (start_batch /
+    finish_batch).  An exchange is three stream operations and a collective whose host cost (~80 us: torch
+    dispatch, RCCL's enqueue) adds to every step of the loop that issues it -- rehearsed with one rank,
+    1.228 -> 1.320 ms per 2^20-point step; a prover with several commitments in flight has several results to
+    hand over at once anyway."""
+
+    def __init__(self, world: int, device, slots: int = 4, batch: int = 1):
         import torch
-        self.world, self.device, self.slots = world, device, slots
+        self.world, self.device, self.slots, self.batch = world, device, slots, batch
         self.on_gpu = device is not None and torch.device(device).type == "cuda"
-        self.bufs = [_Exchange(world, device) for _ in range(slots)]
+        self.bufs = [_Exchange(world, device, batch) for _ in range(slots)]
+        self.count = [0] * slots
         self.busy = [False] * slots
-        self.results: list = [None] * slots
         if self.on_gpu:
             self.stream = torch.cuda.Stream(device=device)
             self.events = [torch.cuda.Event() for _ in range(slots)]
 
     def start(self, part: bytes) -> int:
+        return self.start_batch([part])
+
+    def finish(self, k: int) -> list[bytes]:
+        return self.finish_batch(k)[0]
+
+    def start_batch(self, parts: list[bytes]) -> int:
         import torch
         import torch.distributed as dist
-        if len(part) != 64:
-            raise ValueError("a marshalled G1 point is 64 bytes")
+        if not 1 <= len(parts) <= self.batch or any(len(p) != 64 for p in parts):
+            raise ValueError("1..batch marshalled G1 points of 64 bytes each")
         k = self.busy.index(False)  # ValueError when every slot is outstanding
         ex = self.bufs[k]
+        self.count[k] = len(parts)
+        ex.h_in.numpy()[:64 * len(parts)] = memoryview(b"".join(parts))
         if not self.on_gpu:
-            self.results[k] = ex.run(part)
+            dist.all_gather_into_tensor(ex.d_out, ex.d_in)
         else:
-            ex.h_in.numpy()[:] = memoryview(part)
             with torch.cuda.stream(self.stream):
                 ex.d_in.copy_(ex.h_in, non_blocking=True)
                 work = dist.all_gather_into_tensor(ex.d_out, ex.d_in, async_op=True)
@@ -86,15 +99,15 @@ class AsyncExchange:
         self.busy[k] = True
         return k
 
-    def finish(self, k: int) -> list[bytes]:
+    def finish_batch(self, k: int) -> list[list[bytes]]:
+        """Per call of the batch: the world_size partial points, in rank order."""
         if not self.busy[k]:
             raise ValueError("no exchange outstanding on this ticket")
         self.busy[k] = False
-        if not self.on_gpu:
-            return self.results[k]
-        self.events[k].synchronize()
-        raw = self.bufs[k].h_out.numpy().tobytes()
-        return [raw[64 * i:64 * i + 64] for i in range(self.world)]
+        if self.on_gpu:
+            self.events[k].synchronize()
+        raw, b = self.bufs[k].h_out.numpy().tobytes(), self.batch
+        return [[raw[64 * (b * r + j):64 * (b * r + j) + 64] for r in range(self.world)] for j in range(self.count[k])]
 
 
 def run_pipelined(steps: int, depth: int, submit, wait, ex=None, host_us=None):
@@ -110,15 +123,23 @@ def run_pipelined(steps: int, depth: int, submit, wait, ex=None, host_us=None):
     q, xq, todo, res = [], [], [], None
     host_us = host_us if host_us is not None else [0.0] * 3
 
-    def exchange(drain: bool = False):
+    batch = getattr(ex, "batch", 1) if depth > 1 else 1  # results that travel in one exchange
+
+    def finish_oldest():
         nonlocal res
+        k = xq.pop(0)
+        for ranks in (ex.finish_batch(k) if hasattr(ex, "finish_batch") else [ex.finish(k)]):
+            res = combine(ranks)
+
+    def exchange(drain: bool = False):
         t1 = time.perf_counter()
-        while todo:
+        while len(todo) >= batch or (todo and drain):
             while len(xq) >= depth:  # at most `depth` exchanges outstanding
-                res = combine(ex.finish(xq.pop(0)))
-            xq.append(ex.start(todo.pop(0)))
+                finish_oldest()
+            take = [todo.pop(0) for _ in range(min(batch, len(todo)))]
+            xq.append(ex.start_batch(take) if hasattr(ex, "start_batch") else ex.start(take[0]))
         while xq and (drain or depth == 1):
-            res = combine(ex.finish(xq.pop(0)))
+            finish_oldest()
         host_us[2] += (time.perf_counter() - t1) * 1e6
 
     def collect():

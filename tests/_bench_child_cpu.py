@@ -24,7 +24,7 @@ orc = OracleC()
 n_total = 1 << args.total_log2n
 off, n = sharding.split_even(n_total, world, rank)
 part = orc.msm(orc.synth_bases(bench.SEED_BASES, n, first=off), orc.synth_scalars(bench.SEED_SCALARS, n, first=off))
-ex = sharding.AsyncExchange(world, None)
+ex = sharding.AsyncExchange(world, None, batch=args.depth)  # as bench.py does
 steps = iter(range(args.steps))
 res = sharding.run_pipelined(args.steps, args.depth, lambda: next(steps), lambda t: part, ex)
 print(f"rank {rank} done", file=sys.stderr if rank == 0 else sys.stdout)  # non-zero ranks' stdout must not reach the parent's

@@ -38,7 +38,7 @@ eng = crypto_amd.Engine(local)
 off, n = sharding.split_even(args.n_total, world, rank)
 bases = eng.random_bases(0x5EED0001, n, first=off, flags=crypto_amd.PRECOMPUTE if args.precompute else 0)
 v = eng.fr_random(0x5EED0002, n, first=off)
-ex = sharding.AsyncExchange(world, dev if args.backend == "nccl" else None)
+ex = sharding.AsyncExchange(world, dev if args.backend == "nccl" else None, batch=args.depth)  # as bench.py does
 results = []
 for depth in (args.depth, 1):
     res = sharding.run_pipelined(args.steps, depth, lambda: eng.msm_submit(bases, v.device_ptr(), n), eng.msm_wait, ex)

@@ -151,3 +151,33 @@ def test_run_pipelined_schedule():
                 assert res == (g0 if steps else None)
                 if ex is not None:
                     assert ex.finished == list(range(steps)) and not ex.out and ex.max_out <= max(depth, 1)
+
+    class FakeBatchEx:  # AsyncExchange with batch > 1: up to `batch` results per exchange
+        def __init__(self, batch):
+            self.batch, self.out, self.sizes, self.parts = batch, {}, [], []
+
+        def start_batch(self, parts):
+            assert 1 <= len(parts) <= self.batch
+            k = len(self.sizes)
+            self.sizes.append(len(parts))
+            self.out[k] = list(parts)
+            self.parts += parts
+            return k
+
+        def finish_batch(self, k):
+            return [[p] for p in self.out.pop(k)]
+
+    for depth in (1, 2, 4):
+        for batch in (2, 4):
+            for steps in (0, 1, 5, 9):
+                ex, n = FakeBatchEx(batch), [0]
+
+                def submit():
+                    n[0] += 1
+                    return n[0] - 1
+
+                res = sharding.run_pipelined(steps, depth, submit, lambda t: g0, ex)
+                assert res == (g0 if steps else None) and not ex.out and len(ex.parts) == steps
+                # depth 1 stays strictly sequential (one result per exchange); otherwise full batches and one remainder
+                want = [1] * steps if depth == 1 else [batch] * (steps // batch) + ([steps % batch] if steps % batch else [])
+                assert ex.sizes == want, (depth, batch, steps, ex.sizes)
