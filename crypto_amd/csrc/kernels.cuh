@@ -1,7 +1,7 @@
 // HIP kernels of the BN256 G1 MSM engine (gfx950).  Pipeline of one MSM
 // (vectorPointScalarMul, go/bp/util.go:165-175, go/bppp/util.go:178-196):
 //
-//   k_part<16|20>, k_group_sort(_tl)  two-pass LDS-staged bucket sort (>= 2^18 points; _tl: the 20-bit-window
+//   k_part<16|20>, k_group_sort(_tl)  two-pass LDS-staged bucket sort (>= 2^15 points with a table, 2^17 without; _tl: the 20-bit-window
 //                     path's tile-local records); k_group_count/subscan/place: groups larger than LDS.  Otherwise:
 //   k_tile_sort<0>    signed c-bit digits of every scalar, per-tile LDS bucket histograms
 //   k_tile_scan       per-bucket prefix over tiles;  k_scan1/2/3 or k_scan_small: bucket totals -> offsets
@@ -11,7 +11,8 @@
 //   k_bucket_fix      joins the partial sums of buckets that straddle thread chunks (quad per bucket);
 //   k_fix_boundary    the same seen from the chunk boundaries (lane per boundary; 2^19 buckets);
 //   k_heavy           buckets with many partial sums (skewed scalars)
-//   k_fold_lane, k_fold   log-depth bucket reduction: T = sum B_b and G_k = sum_{bit k of b} B_b
+//   k_fold_lane2, k_fold_lane, k_fold   log-depth bucket reduction: T = sum B_b and G_k = sum_{bit k of b} B_b
+//                     (lane per four inputs / per addition for the wide first levels, quad per addition after)
 //   k_pack_results    canonical XYZZ words of T, G_0..G_{c-2} for the host Horner tail
 //   k_fold_small      all levels and the packing of a <= 512-bucket set in one launch
 //
