@@ -7,7 +7,7 @@
 // operands of the 32 x 32 + 64 multiply-add.  ceil((2 * 256 - 1) / 29) = 18 outer iterations, ~20 000
 // instructions, no data-dependent branch; a^(p-2) is 383 field multiplications, ~78 000 instructions.  The
 // normalisation of a handful of points (a prover's small rounds) is one inversion's latency on a lone wave:
-// 173 -> 52 us per k_batch_to_affine call.
+// 173 -> 60 us per k_batch_to_affine call.
 //
 // Plain C++ with no dependency on the device headers: bn256msm.hip compiles it for the GPU (INV29_FN =
 // __device__), tests/inv29_host_test.cpp for the CPU, where it is checked against a^(p-2) on millions of values.
