@@ -10,7 +10,8 @@
 // 173 -> 60 us per k_batch_to_affine call.
 //
 // Plain C++ with no dependency on the device headers: bn256msm.hip compiles it for the GPU (INV29_FN =
-// __device__), tests/inv29_host_test.cpp for the CPU, where it is checked against a^(p-2) on millions of values.
+// __device__), tests/inv29_host_test.cpp for the CPU, where x * inverse(x) = 1 is checked in the library's host
+// field arithmetic on edge values and millions of random ones (6 * 10^7 once; 3 * 10^5 in every CPU test run).
 // The caller checks the result's flag and falls back to a^(p-2): inverse() returns false when b did not reach 1
 // (x = 0, or, against the paper's proof, an input that needs more iterations).
 #pragma once
