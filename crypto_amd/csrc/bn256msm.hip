@@ -190,8 +190,9 @@ struct bn256_ctx {
   u32* h_pack;      // pinned
   size_t h_pack_cap;
   u32* d_err;
-  u32* d_heavy;     // [0] heavy queue length, [1] split buckets, [2..] tickets (kernels.cuh k_heavy), then the
-                    // 1024 group totals of the two-pass sort: everything a pass needs zeroed, one memset
+  u32* d_heavy;     // the counter block of kernels.cuh (HEAVY_*): queue lengths, tickets, the group totals of the
+                    // two-pass sort (two arrays, used alternately); zeroed once, then kept clear by heavy_clear
+  int gtotal_parity;  // which of the two the next two-pass sort uses
   u32* h_err;       // pinned
   u32* d_flags;     // MSM_FLAG_* of the call in flight (kernels.cuh): the last two words of d_heavy's block; the
                     // packing kernel appends them to the packed results, so they reach the host with h_pack
@@ -307,13 +308,14 @@ static int ctx_init(bn256_ctx* ctx) {
   for (auto& e : ctx->ev) HIPCHK(hipEventCreate(&e));
   for (int i = 0; i < 2; i++) {
     hipError_t e = i == 0 ? pool::dev_malloc((void**)&ctx->d_err, 256)
-                          : pool::dev_malloc((void**)&ctx->d_heavy, HEAVY_WORDS * sizeof(u32));
+                          : pool::dev_malloc((void**)&ctx->d_heavy, HEAVY_ALLOC_WORDS * sizeof(u32));
     if (e != hipSuccess) {
       ctx_note_hip(e, __LINE__);
       return e == hipErrorOutOfMemory ? BN256_ENOMEM : BN256_EHIP;
     }
   }
   ctx->d_flags = ctx->d_heavy + HEAVY_BASE;
+  HIPCHK(hipMemset(ctx->d_heavy, 0, HEAVY_ALLOC_WORDS * sizeof(u32)));  // the kernels keep it clear from here on (heavy_clear)
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
   HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
@@ -789,7 +791,19 @@ struct msm_src {
 // A table-less call has one term (callers gather several into one first).  With hold_stream the host
 // never waits for the stream here (a call of several passes then reports the phase times of its last
 // pass only).
+static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool hold_stream, msm_pending* pend);
+// The counter block is kept clear by the kernels themselves (heavy_clear, kernels.cuh); a call that fails
+// part-way may leave it otherwise, so a failed enqueue drains the stream and zeroes it again.
 static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool hold_stream, msm_pending* pend) {
+  const int rc = msm_enqueue_srcs_impl(ctx, srcs, nsrc, hold_stream, pend);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemset(ctx->d_heavy, 0, HEAVY_ALLOC_WORDS * sizeof(u32));
+    ctx->gtotal_parity = 0;
+  }
+  return rc;
+}
+static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool hold_stream, msm_pending* pend) {
   using namespace hostg1;
   pend->empty = true;
   for (float& f : ctx->last_ms) f = 0.f;
@@ -1014,7 +1028,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       HIPCHK(hipStreamWaitEvent(s, ctx->ev_copy[cj & 1], 0));
     }
     MSM_MARK(0);
-    HIPCHK(hipMemsetAsync(heavy_count, 0, (ch == 0 ? HEAVY_WORDS : HEAVY_BASE) * sizeof(u32), s));
+    const u32 first_pass = ch == 0 ? 1u : 0u;  // the pass's first kernel clears the counters (heavy_clear), the flags with it here
     // a pass uses the two-pass sort only with all 256 tiles (>= 2^18 points); the ragged last pass
     // of a chunked call may fall back to the single-pass kernels
     const bool two = two_pass && n_ch >= two_min;
@@ -1029,16 +1043,20 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
       hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(SCAN_BLOCK), 0, s, out, (u32)m, (const u32*)blocksum);
     };
     if (two) {
-      u32* gtotal = heavy_count + 2 + HEAVY_SLOTS;
+      u32* gtotal = heavy_count + (ctx->gtotal_parity ? HEAVY_GTOTAL2 : HEAVY_GTOTAL);
+      u32* gtotal_next = heavy_count + (ctx->gtotal_parity ? HEAVY_GTOTAL : HEAVY_GTOTAL2);
+      ctx->gtotal_parity ^= 1;
       u32* loc = (u32*)ctx->ws[WS_GBASE];
       u32* subhist = (u32*)ctx->ws[WS_SUBHIST];
       const u32 nt2 = tiles2_for(n_ch), TS = nt2 / SORT2_S;
       if (wide)
         hipLaunchKernelGGL((k_part<20, true>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W, (u32)sc_stride,
-                           G2, LB2, ibits, key_stride, top_scale, (u32)off_ch, (u32)stride, gtotal, loc, rank);
+                           G2, LB2, ibits, key_stride, top_scale, (u32)off_ch, (u32)stride, gtotal, loc, rank, heavy_count,
+                           gtotal_next, first_pass);
       else
         hipLaunchKernelGGL((k_part<16, false>), dim3(nt2), dim3(1024), lds_part, s, sc_ch, (u32)n_ch, (u32)W,
-                           (u32)sc_stride, G2, LB2, ibits, key_stride, top_scale, (u32)off_ch, (u32)stride, gtotal, loc, rank);
+                           (u32)sc_stride, G2, LB2, ibits, key_stride, top_scale, (u32)off_ch, (u32)stride, gtotal, loc, rank,
+                           heavy_count, gtotal_next, first_pass);
       MSM_MARK(1);
       MSM_MARK(2);
       const u32 init_inf = ch == 0 ? 1u : 0u;  // buckets without entries: infinity on the call's first pass
@@ -1064,10 +1082,12 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<false>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
                          (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, top_scale,
-                         hist, (const u32*)nullptr, (u32*)nullptr);
+                         hist, (const u32*)nullptr, (u32*)nullptr, heavy_count, first_pass);
       MSM_MARK(1);
       hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
     } else {
+      // (bucket arrays beyond LDS, c >= 17 without the two-pass sort: never chosen by default)
+      HIPCHK(hipMemsetAsync(heavy_count, 0, (first_pass ? HEAVY_WORDS : HEAVY_BASE) * sizeof(u32), s));
       HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
       hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
                          (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, top_scale, counts, rank,
@@ -1080,7 +1100,7 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
     if (use_lds) {
       hipLaunchKernelGGL(k_tile_sort<true>, dim3(ntiles, nsets), dim3(1024), lds_bytes, s, sc_ch, (u32)n_ch, (u32)c,
                          (u32)W, nb, (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, tile_len, (u32)sc_stride, top_scale,
-                         hist, (const u32*)offsets, sval);
+                         hist, (const u32*)offsets, sval, heavy_count, first_pass);
     } else {
       hipLaunchKernelGGL(k_recode<true>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
                          (u32)precomp, (u32)off_ch, (u32)stride, (u32)b->n, (u32)sc_stride, top_scale, counts, rank,

@@ -216,6 +216,29 @@ __device__ __forceinline__ u32 recode_carry_into(const u32 k[8], u32 w, u32 c) {
   return 0u;
 }
 
+#define HEAVY_SLOTS 1024u      // buckets reduced by HEAVY_PARTS workgroups per pass (2T / 4096 <= 256 at the default chunk length)
+// The context's counter block: [0] heavy queue length, [1] split buckets, [2, 2 + HEAVY_SLOTS) tickets, 1024
+// group totals of the two-pass sort, the medium queue's length, then the two MSM_FLAG words of the call;
+// behind the block a second array of group totals (HEAVY_GTOTAL2).
+#define HEAVY_GTOTAL (2u + HEAVY_SLOTS)
+#define HEAVY_MEDIUM (HEAVY_GTOTAL + 1024u)  // length of the medium queue (k_fix_boundary)
+#define HEAVY_BASE (HEAVY_MEDIUM + 2u)
+#define HEAVY_WORDS (HEAVY_BASE + 2u)
+#define HEAVY_GTOTAL2 HEAVY_WORDS
+#define HEAVY_ALLOC_WORDS (HEAVY_WORDS + 1024u)
+// No memset in front of a pass (hipMemsetAsync is two fill kernels; the device starts ~21 us after the call is
+// entered, a kernel launch ~7 us): block 0 of the pass's FIRST kernel clears what only later kernels of the
+// pass use -- queue lengths, tickets, on a call's first pass the flags -- and, for the two-pass sort, the
+// group totals of the NEXT pass: they alternate between two arrays, this pass's was cleared by the pass
+// before it (both are zero when the context is made).
+__device__ __forceinline__ void heavy_clear(u32* __restrict__ heavy_count, u32* __restrict__ gtotal_next, u32 first_pass) {
+  for (u32 j = threadIdx.x; j < HEAVY_GTOTAL; j += blockDim.x) heavy_count[j] = 0;
+  if (threadIdx.x < 2u) heavy_count[HEAVY_MEDIUM + threadIdx.x] = 0;
+  if (first_pass && threadIdx.x < 2u) heavy_count[HEAVY_BASE + threadIdx.x] = 0;
+  if (gtotal_next)
+    for (u32 j = threadIdx.x; j < 1024u; j += blockDim.x) gtotal_next[j] = 0;
+}
+
 // Wide-window tables (bases_precompute): the top table level of point i holds (1 / s_i) 2^(c (W-1)) P_i with
 // s_i = top_scale - (i mod TOP_SCALES), and the point's top digit is multiplied by s_i.  top_scale = 1: nothing of this.
 #define TOP_SCALES 8u
@@ -227,9 +250,11 @@ template <bool SCATTER>
 __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ scalars_be, u32 n, u32 c, u32 W, u32 nb,
                                                     u32 precomp, u32 base_off, u32 pt_stride, u32 level_stride, u32 tile_len,
                                                     u32 sc_stride, u32 top_scale, u32* __restrict__ hist,
-                                                    const u32* __restrict__ offsets, u32* __restrict__ sval) {
+                                                    const u32* __restrict__ offsets, u32* __restrict__ sval,
+                                                    u32* __restrict__ heavy_count, u32 first_pass) {
   extern __shared__ u32 lds[];
   const u32 tile = blockIdx.x, set = blockIdx.y, ntiles = gridDim.x;
+  if (!SCATTER && tile == 0 && set == 0) heavy_clear(heavy_count, nullptr, first_pass);
   u32* h = hist + ((size_t)set * ntiles + tile) * nb;
   if (!SCATTER) {
     for (u32 j = threadIdx.x; j < nb; j += blockDim.x) lds[j] = 0;
@@ -334,10 +359,13 @@ template <int C, bool TL>
 __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scalars_be, u32 n, u32 W, u32 sc_stride,
                                                u32 G, u32 LB, u32 ibits, u32 key_stride, u32 top_scale,
                                                u32 base_off, u32 pt_stride, u32* __restrict__ gtotal,
-                                               u32* __restrict__ loc, u32* __restrict__ rec) {
+                                               u32* __restrict__ loc, u32* __restrict__ rec,
+                                               u32* __restrict__ heavy_count, u32* __restrict__ gtotal_next,
+                                               u32 first_pass) {
   extern __shared__ u32 lds[];  // cnt[G], cur[G], then per-wave histograms [16][G] aliased by stage[TCAP]
   constexpr u32 c = C;
   const u32 tile = blockIdx.x, wave = threadIdx.x >> 6;
+  if (tile == 0) heavy_clear(heavy_count, gtotal_next, first_pass);
   u32* cnt = lds;
   u32* cur = lds + G;
   u32* hist = lds + 2 * G;
@@ -877,13 +905,6 @@ __global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in,
 #define FIX_CAP 32
 #define HEAVY_SPLIT_MIN 4096u  // partials above which one bucket is reduced by HEAVY_PARTS workgroups
 #define HEAVY_PARTS 64u
-#define HEAVY_SLOTS 1024u      // such buckets per pass (2T / 4096 <= 256 at the default chunk length)
-// The context's counter block: [0] heavy queue length, [1] split buckets, [2, 2 + HEAVY_SLOTS) tickets, 1024
-// group totals of the two-pass sort -- HEAVY_BASE words cleared before every pass -- then the two
-// MSM_FLAG words of the call, cleared with its first pass only (one memset either way).
-#define HEAVY_MEDIUM (2u + HEAVY_SLOTS + 1024u)  // length of the medium queue (k_fix_boundary)
-#define HEAVY_BASE (HEAVY_MEDIUM + 2u)
-#define HEAVY_WORDS (HEAVY_BASE + 2u)
 // Thread t owns the sorted entries [t*K, (t+1)*K); bucket boundaries come from offsets[].
 // Runs of one bucket are summed with mixed additions.  A run that neither continues from
 // thread t-1 nor into thread t+1 is a complete bucket; otherwise it is a partial: slot 2t if
