@@ -6,6 +6,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+
+# Every lane (call in flight) has a HIP stream of its own, and a HIP process serves all of its streams from
+# GPU_MAX_HW_QUEUES hardware queues (4 by default): two lanes on one queue run one after the other
+# (tools/probe/stream_probe.hip).  The runtime reads the variable when it initialises, so it
+# is raised here, at import, before this package makes the first HIP call -- WNLA 2^20 22.8 -> 19.7 ms, go/bp
+# N = 64 prove 7.5 -> 7.1 ms, four 2^20-point calls in flight +0.6...2 %.  CRYPTO_AMD_HW_QUEUES=0 leaves the
+# environment alone; a C or Go caller sets the variable itself.
+_want_queues = int(os.environ.get("CRYPTO_AMD_HW_QUEUES", "8"))
+if _want_queues and int(os.environ.get("GPU_MAX_HW_QUEUES") or 4) < _want_queues:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(_want_queues)
 LIB_PATH = os.environ.get("BN256MSM_LIB") or os.path.join(_HERE, "libbn256msm.so")  # override: A/B builds
 
 EXPORTS = [
