@@ -42,10 +42,13 @@ import statistics
 import sys
 import time
 
-# before anything loads the HIP runtime (see above); BENCH_HW_QUEUES=0 leaves the environment's value alone
-if os.environ.get("BENCH_HW_QUEUES", "8") != "0":
-    os.environ["GPU_MAX_HW_QUEUES"] = str(max(int(os.environ.get("GPU_MAX_HW_QUEUES") or 4),
-                                              int(os.environ.get("BENCH_HW_QUEUES", "8"))))
+# before anything loads the HIP runtime (see above); BENCH_HW_QUEUES=0 leaves the environment's value alone.
+# A rank of a multi-GPU run has more streams (the exchange's side stream, RCCL's own): 16 queues there --
+# rehearsed with one rank and the exchange forced, 794-810 Mpts/s on 8 queues, 841-847 on 16.
+_queues = os.environ.get("BENCH_HW_QUEUES") or (
+    "16" if int(os.environ.get("WORLD_SIZE") or 1) > 1 or os.environ.get("BENCH_FORCE_DIST") else "8")
+if _queues != "0":
+    os.environ["GPU_MAX_HW_QUEUES"] = str(max(int(os.environ.get("GPU_MAX_HW_QUEUES") or 4), int(_queues)))
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
