@@ -187,7 +187,8 @@ struct bn256_ctx {
   // bn256_msm_dev_noalloc: while set, ws_reserve carves ws[] from the device's static scratch array
   bool fixed_ws;
   size_t fixed_used;
-  u32* h_pack;      // pinned
+  u32* h_pack;      // pinned, mapped: the packing kernel writes the call's results straight into it
+  u32* d_hpack;     // h_pack as the device sees it
   size_t h_pack_cap;
   u32* d_err;
   u32* d_heavy;     // the counter block of kernels.cuh (HEAVY_*): queue lengths, tickets, the group totals of the
@@ -315,10 +316,16 @@ static int ctx_init(bn256_ctx* ctx) {
     }
   }
   ctx->d_flags = ctx->d_heavy + HEAVY_BASE;
-  HIPCHK(hipMemset(ctx->d_heavy, 0, HEAVY_ALLOC_WORDS * sizeof(u32)));  // the kernels keep it clear from here on (heavy_clear)
+  // the kernels keep it clear from here on (heavy_clear).  On the context's own stream and waited for: a
+  // hipMemset runs on the null stream, which a non-blocking stream does not wait for -- the first pass of a
+  // fresh lane could start before it and have its group totals zeroed under it (seen once the lanes had a
+  // hardware queue each)
+  HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, HEAVY_ALLOC_WORDS * sizeof(u32), ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipHostMalloc(&ctx->h_err, 256));
   ctx->h_pack_cap = 64 * 32 * sizeof(u32) * 32;
-  HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap));
+  HIPCHK(hipHostMalloc(&ctx->h_pack, ctx->h_pack_cap, hipHostMallocMapped | hipHostMallocCoherent));
+  HIPCHK(hipHostGetDevicePointer((void**)&ctx->d_hpack, ctx->h_pack, 0));
   // the sort kernels' dynamic LDS above 48 KiB (per function and device; set here so that no MSM
   // call carries set-up work)
   HIPCHK(hipFuncSetAttribute((const void*)k_part<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
@@ -798,7 +805,8 @@ static int msm_enqueue_srcs(bn256_ctx* ctx, const msm_src* srcs, int nsrc, bool 
   const int rc = msm_enqueue_srcs_impl(ctx, srcs, nsrc, hold_stream, pend);
   if (rc) {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemset(ctx->d_heavy, 0, HEAVY_ALLOC_WORDS * sizeof(u32));
+    (void)hipMemsetAsync(ctx->d_heavy, 0, HEAVY_ALLOC_WORDS * sizeof(u32), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     ctx->gtotal_parity = 0;
   }
   return rc;
@@ -950,7 +958,6 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   if ((rc = ws_reserve(ctx, WS_BUCKETS, nbt * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * Tmax * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_LASTB, Tmax * 4))) return rc;
-  if ((rc = ws_reserve(ctx, WS_PACK, (npack * 32 + 2) * 4))) return rc;
   if ((npack * 32 + 2) * 4 > ctx->h_pack_cap) return BN256_EINVAL;
 
   u32* counts = (u32*)ctx->ws[WS_COUNTS];
@@ -962,7 +969,6 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   xyzz_mem* buckets = (xyzz_mem*)ctx->ws[WS_BUCKETS];
   xyzz_mem* sum_buckets = buckets;  // later passes add into the same array (k_accumulate's add_prev)
   xyzz_mem* partials = (xyzz_mem*)ctx->ws[WS_PARTIALS];
-  u32* d_pack = (u32*)ctx->ws[WS_PACK];
   u32* heavy_count = ctx->d_heavy;
   u32* heavy_list = (u32*)ctx->ws[WS_SKEY];
   hipStream_t s = ctx->stream;
@@ -1149,7 +1155,7 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   }
   if (nb <= FOLD_SMALL_MAX_NB) {  // every level and the packing in one launch (small calls: launch-bound)
     const u32 fold_threads = std::min<u32>(768u, std::max<u32>(64u, 2u * nb));  // nb / 2 quads at the widest level
-    hipLaunchKernelGGL(k_fold_small, dim3(nsets), dim3(fold_threads), 0, s, sum_buckets, nsets, nb, q, d_pack,
+    hipLaunchKernelGGL(k_fold_small, dim3(nsets), dim3(fold_threads), 0, s, sum_buckets, nsets, nb, q, ctx->d_hpack,
                        (const u32*)d_flags);
   } else {
   for (u32 l = 0; l < q; l++) {
@@ -1170,11 +1176,11 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
       hipLaunchKernelGGL(k_fold, dim3(nblocks(threads * 4, 64)), dim3(64), 0, s, sum_buckets, nsets, nb, l);
   }
   hipLaunchKernelGGL(k_pack_results, dim3(nblocks(npack, 64)), dim3(64), 0, s, (const xyzz_mem*)sum_buckets, nsets, nb, q,
-                     d_pack, (const u32*)d_flags);
+                     ctx->d_hpack, (const u32*)d_flags);
   }
+  // results + flags are in the mapped pinned buffer when the stream has drained: no copy kernel behind the packing
   MSM_MARK(6);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(ctx->h_pack, d_pack, (npack * 32 + 2) * 4, hipMemcpyDeviceToHost, s));  // results + flags
   pend->empty = false;
   pend->c = c;
   pend->q = q;
