@@ -2248,8 +2248,11 @@ extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* cons
   if (!any) return BN256_OK;
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ws_reserve(ctx, WS_TMP, need))) return rc;
-  uint8_t* d_out = (uint8_t*)ctx->ws[WS_TMP];              // k results, then every product's partial sums
-  uint8_t* cur = d_out + (((size_t)k * 32 + 255) & ~(size_t)255);
+  // k results, then every product's partial sums.  The results go straight into the context's mapped pinned
+  // buffer when they fit it (they do: 2048 products): no copy behind the summing kernel (see msm_enqueue_srcs)
+  const bool direct = (size_t)k * 32 <= ctx->h_pack_cap;
+  uint8_t* d_out = direct ? (uint8_t*)ctx->d_hpack : (uint8_t*)ctx->ws[WS_TMP];
+  uint8_t* cur = (uint8_t*)ctx->ws[WS_TMP] + (((size_t)k * 32 + 255) & ~(size_t)255);
   // products in launches of FR_DOT_BATCH; an empty product (nblk = 0) sums to zero
   for (int i0 = 0; i0 < k; i0 += FR_DOT_BATCH) {
     const int kb = std::min(k - i0, (int)FR_DOT_BATCH);
@@ -2283,8 +2286,9 @@ extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* cons
     hipLaunchKernelGGL(k_fr_sum, dim3(kb), dim3(256), 0, ctx->stream, batch, d_out + 32 * (size_t)i0);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out_be, d_out, (size_t)k * 32, hipMemcpyDeviceToHost, ctx->stream));  // one copy,
-  HIPCHK(hipStreamSynchronize(ctx->stream));                                                   // one wait
+  if (!direct) HIPCHK(hipMemcpyAsync(out_be, d_out, (size_t)k * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // one wait for all products
+  if (direct) memcpy(out_be, ctx->h_pack, (size_t)k * 32);
   return BN256_OK;
 }
 
