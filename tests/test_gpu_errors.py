@@ -78,3 +78,27 @@ def test_drain_voids_lost_tickets(eng, orc):
     finally:
         h.free()
         v.free()
+
+
+def test_first_calls_of_fresh_lanes(orc):
+    """A context's lanes are made at their first use, and whatever their set-up leaves in flight must be done
+    before the lane's first pass runs (the one-time clearing of a new context's counter block once ran on the
+    null stream, which a lane's non-blocking stream does not wait for: the first call of a fresh lane then
+    lost its group totals two runs in three).  New contexts, all four lanes submitted at once -- three of them
+    are made while the first one's call is running --, every result against the closed form."""
+    n = (1 << 19) + 77  # long enough that lanes 1..3 are made while lane 0's call keeps the chip busy
+    seed_b, seed_s = 0xF1E5, 0xF1E6
+    for rep in range(4):
+        e = crypto_amd.Engine(0)
+        try:
+            h = e.random_bases(seed_b + rep, n, flags=crypto_amd.PRECOMPUTE)
+            v = e.fr_random(seed_s + rep, n)
+            ks = orc.synth_base_scalars(seed_b + rep, n)
+            want = orc.g0_mul(orc.fr_dot(b"".join(x.to_bytes(32, "big") for x in v.download()), ks))
+            tickets = [e.msm_submit(h, v.device_ptr(), n) for _ in range(crypto_amd.ASYNC_LANES)]
+            assert [e.msm_wait(t) for t in tickets] == [want] * crypto_amd.ASYNC_LANES, f"context {rep}"
+            assert e.msm_dev(h, v.device_ptr(), n) == want
+            h.free()
+            v.free()
+        finally:
+            e.close()
