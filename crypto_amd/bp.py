@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BPAMD_LIB") or os.path.join(_HERE, "libbpamd.so")  # override: A/B builds
 EXPORTS = ["bp_schnorr_msg", "bp_schnorr_multisig", "bp_schnorr_sign_det", "bp_schnorr_verify_batch",
            "bp_veca_encrypt_det", "bp_veca_verify", "bp_veca_decrypt", "bp_setup", "bp_prove", "bp_verify", "bp_prove_det", "bp_verify_det", "bp_inner_product_roundtrip", "bp_keccak256", "bp_last_error",
-           "bp_wnla_det", "bp_wnla_synthetic", "bp_ac_det"]
+           "bp_wnla_det", "bp_wnla_synthetic", "bp_ac_det", "bp_ac_wlw"]
 _bp = None
 
 
@@ -41,6 +41,7 @@ def load() -> C.CDLL:
     lib.bp_wnla_synthetic.argtypes = [vp, C.c_uint64, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int)]
     lib.bp_ac_det.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(AcCircuit), C.c_char_p, sz, C.POINTER(sz)]
+    lib.bp_ac_wlw.argtypes = [C.POINTER(AcCircuit), C.c_char_p]
     cp = C.c_char_p
     lib.bp_schnorr_msg.argtypes = [cp, sz, cp]
     lib.bp_schnorr_multisig.argtypes = [cp, cp, cp, cp, cp, cp]
@@ -231,6 +232,25 @@ class ArithmeticCircuit:
         res["wnla_ok"] = rc == 0
         assert pos == len(raw)
         return res
+
+
+def wl_times_w(pub: dict, prv: dict) -> list:
+    """matrixMulOnVector(w, Wl), w = wl || wr || wo (go/bppp/util.go:311-319): the "Wl*w" the reference's circuit
+    tests print (go/bppp/docs_test.go:326).  The C++ mirror's host Fr arithmetic (bp_ac_wlw); no GPU needed."""
+    lib = load()
+    n_order = 0x8fb501e34aa387f9aa6fecb86184dc212e8d8e12f82b39241a2ef45b57ac7261
+
+    def sc(xs):
+        return b"".join((int(x) % n_order).to_bytes(32, "big") for x in xs)
+
+    c = AcCircuit()
+    c.Nm, c.Nl, c.Nv, c.Nw, c.No, c.K = pub["Nm"], pub["Nl"], pub["Nv"], pub["Nw"], pub["No"], pub["K"]
+    c.Wl, c.wl, c.wr, c.wo = sc([x for row in pub["Wl"] for x in row]), sc(prv["wl"]), sc(prv["wr"]), sc(prv["wo"])
+    out = C.create_string_buffer(32 * pub["Nl"])
+    rc = lib.bp_ac_wlw(C.byref(c), out)
+    if rc:
+        raise RuntimeError(f"bp_ac_wlw rc={rc}: {lib.bp_last_error().decode()}")
+    return [int.from_bytes(out.raw[32 * i:32 * i + 32], "big") for i in range(pub["Nl"])]
 
 
 def parse_proof(raw: bytes) -> dict:

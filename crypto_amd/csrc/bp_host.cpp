@@ -1182,6 +1182,11 @@ FrVec vectorMulOnMatrix(const FrVec& a, const FrMat& m) {  // go/bppp/util.go:29
   }
   return r;
 }
+FrVec matrixMulOnVector(const FrVec& a, const FrMat& m) {  // go/bppp/util.go:311-319
+  FrVec r;
+  for (const FrVec& row : m) r.push_back(vectorMulPP(a, row));
+  return r;
+}
 FrMat diagInv(const Fr& x, int n) {  // go/bppp/util.go:321-340
   FrMat r(n, FrVec(n, kFrZero));
   Fr inv = fr_inv(x), val = inv;
@@ -1754,6 +1759,32 @@ extern "C" int bp_ac_det(bn256_ctx* ctx, uint64_t seed, int pre_draws, int post_
   } catch (const std::exception& e) {
     g_err = e.what();
     if (ctx) (void)bn256_ctx_drain(ctx);  // a ticket lost to the exception must not keep its lane busy
+    return BP_EFAIL;
+  }
+}
+
+// matrixMulOnVector(w, Wl) with w = wl || wr || wo: the vector the reference's circuit tests print as
+// "Wl*w" (go/bppp/docs_test.go:326; util.go:311-319) -- the one multi-entry Fr answer the reference's
+// tests record (docs_test.go:365).  Host Fr arithmetic only; out: Nl x 32 bytes.
+extern "C" int bp_ac_wlw(const bp_ac_circuit* c, uint8_t* out) {
+  try {
+    if (!c || !out || c->Nm < 1 || c->Nl < 1 || c->No < 0 || c->Nw != 2 * c->Nm + c->No) return BN256_EINVAL;
+    if (!c->Wl || !c->wl || !c->wr || (!c->wo && c->No)) return BN256_EINVAL;
+    FrVec w;
+    for (int i = 0; i < c->Nm; i++) w.push_back(fr_from_be(c->wl + 32 * (size_t)i));
+    for (int i = 0; i < c->Nm; i++) w.push_back(fr_from_be(c->wr + 32 * (size_t)i));
+    for (int i = 0; i < c->No; i++) w.push_back(fr_from_be(c->wo + 32 * (size_t)i));
+    FrMat Wl;
+    for (int i = 0; i < c->Nl; i++) {
+      FrVec row(c->Nw);
+      for (int j = 0; j < c->Nw; j++) row[j] = fr_from_be(c->Wl + 32 * ((size_t)i * c->Nw + j));
+      Wl.push_back(row);
+    }
+    FrVec r = matrixMulOnVector(w, Wl);
+    for (int i = 0; i < c->Nl; i++) fr_to_be(out + 32 * (size_t)i, r[i]);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
     return BP_EFAIL;
   }
 }

@@ -96,6 +96,11 @@ typedef struct {
 int bp_ac_det(bn256_ctx* ctx, uint64_t seed, int pre_draws, int post_draws, const bp_ac_circuit* c, uint8_t* out,
               size_t cap, size_t* out_len);
 
+/* matrixMulOnVector(w, Wl), w = wl || wr || wo (go/bppp/util.go:311-319): the "Wl*w" vector the reference's
+ * circuit tests print (go/bppp/docs_test.go:326) and record for TestAC3 (:365).  Host arithmetic only (usable
+ * without a GPU); only Nm, Nl, No, Nw, Wl, wl, wr, wo of the circuit are read.  out: Nl x 32 bytes BE. */
+int bp_ac_wlw(const bp_ac_circuit* c, uint8_t* out);
+
 /* BASELINE.json configs[3] shape: the same argument over synthetic commitment vectors of length
  * nl / nn (e.g. 2^20); reports wall ms for set-up and for the rounds, and the round count. */
 int bp_wnla_synthetic(bn256_ctx* ctx, uint64_t seed, size_t nl, size_t nn, double* ms_setup, double* ms_run,

@@ -232,3 +232,26 @@ def test_multi_dot_and_multi_fold_match_the_single_calls(eng):
         want_n = ref.vector_add_bppp(ref.vector_mul_on_scalar(n0, roinv), ref.vector_mul_on_scalar(n1, y))
         assert outs[2].download() == want_n
     assert eng.fr_dot_multi([]) == [] and eng.fr_fold_multi([]) == []
+
+
+def test_wl_times_w_of_test_ac3_on_the_device_matches_the_reference_held_vector(eng):
+    """go/bppp/docs_test.go:365 records the 32 values of matrixMulOnVector(w, Wl) for TestAC3 (e = 2): here every
+    row is a device inner product (bn256_fr_dot_multi over views of one resident matrix), compared with the
+    literal vector (tests/golden/ref_wlw_ac3.json) -- the one place the device's Fr kernels meet a known answer
+    that the reference itself holds."""
+    import json
+    import os
+    import ac_cases
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wlw_ac3.json")) as f:
+        want = [int(x) for x in json.load(f)["wl_times_w"]]
+    _, _, _, pub, prv = ac_cases.test_ac3()
+    w = prv["wl"] + prv["wr"] + prv["wo"]
+    nw, nl = pub["Nw"], pub["Nl"]
+    hw = eng.fr_upload(w)
+    hm = eng.fr_upload([x for row in pub["Wl"] for x in row])
+    got = []
+    for r0 in range(0, nl, 8):  # up to 8 inner products per device call
+        got += eng.fr_dot_multi([(hw, 0, 1, nw, hm, r * nw, 1, nw) for r in range(r0, min(r0 + 8, nl))])
+    assert got == want
+    hw.free()
+    hm.free()

@@ -23,6 +23,37 @@ def test_group_order_pinned_by_reference_docs_test():
     assert ref.fsub(0, 4) == ref.N - 4
 
 
+def _ref_wlw_ac3():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_wlw_ac3.json")) as f:
+        return [int(x) for x in json.load(f)["wl_times_w"]]
+
+
+def test_wl_times_w_of_test_ac3_all_32_entries_as_the_reference_records_them():
+    """go/bppp/docs_test.go:365: the comment under TestAC3 holds the 32 values its run printed for
+    matrixMulOnVector(w, Wl) (:326) with e = values(1)[0] = 2 -- the largest known answer the reference has for
+    this path (tests/golden/ref_wlw_ac3.json, extracted by tests/golden/make_ref_wlw.py).  Lines :366 and
+    :492-493 are stale prints (an older circuit; the TestAC3 comment pasted under TestAC4) and pin nothing."""
+    import ac_cases
+    want = _ref_wlw_ac3()
+    assert len(want) == 32
+    _, _, _, pub, prv = ac_cases.test_ac3()
+    got = ref.matrix_mul_on_vector(prv["wl"] + prv["wr"] + prv["wo"], pub["Wl"])
+    assert got == want
+    # the circuit identity the reference prints next to it (:324): Wl*w + v + al = 0
+    assert ref.vector_add(ref.vector_add(got, prv["v"][0]), pub["Al"]) == [0] * 32
+
+
+def test_wl_times_w_of_test_ac3_from_the_cpp_mirror():
+    """The same 32 values from the C++ host mirror (bp_ac_wlw: bp_host.cpp's matrixMulOnVector over its own
+    Montgomery Fr) -- loads libbpamd.so, calls no GPU code."""
+    import ac_cases
+    from crypto_amd import bp
+    _, _, _, pub, prv = ac_cases.test_ac3()
+    assert bp.wl_times_w(pub, prv) == _ref_wlw_ac3()
+
+
 def test_scalar_helper_known_answers():
     # go/bp/docs_test.go:390-392: a=[4,5,10,1], b=[2,1,2,10]; the reference's comment says
     # "4 + 5 + 20 + 10 = 39" but 4*2 = 8, so vectorMul returns 43 (the test only compares
