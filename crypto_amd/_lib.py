@@ -13,9 +13,27 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is raised here, at import, before this package makes the first HIP call -- WNLA 2^20 22.8 -> 19.7 ms, go/bp
 # N = 64 prove 7.5 -> 7.1 ms, four 2^20-point calls in flight +0.6...2 %.  CRYPTO_AMD_HW_QUEUES=0 leaves the
 # environment alone; a C or Go caller sets the variable itself.
+# SIDE EFFECT: the variable is process-wide, so torch's and RCCL's streams in the same process are served from
+# the raised number of queues too.  It has NO effect when the HIP runtime was initialised before this import
+# (a caller that ran torch.cuda first): that case is detected below and reported with a warning, because the
+# figures quoted in DESIGN.md for several calls in flight depend on the raised value.
 _want_queues = int(os.environ.get("CRYPTO_AMD_HW_QUEUES", "8"))
 if _want_queues and int(os.environ.get("GPU_MAX_HW_QUEUES") or 4) < _want_queues:
-    os.environ["GPU_MAX_HW_QUEUES"] = str(_want_queues)
+    _hip_up = False
+    try:
+        import sys as _sys
+        _t = _sys.modules.get("torch")
+        _hip_up = bool(_t is not None and _t.cuda.is_initialized())
+    except Exception:  # pragma: no cover
+        _hip_up = False
+    if _hip_up:
+        import warnings
+        warnings.warn(
+            f"crypto_amd: the HIP runtime was initialised before this import, so GPU_MAX_HW_QUEUES={_want_queues} "
+            "cannot take effect in this process (lanes will share hardware queues and overlap less); import "
+            "crypto_amd before the first torch.cuda call, or export GPU_MAX_HW_QUEUES yourself", RuntimeWarning)
+    else:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(_want_queues)
 LIB_PATH = os.environ.get("BN256MSM_LIB") or os.path.join(_HERE, "libbn256msm.so")  # override: A/B builds
 
 EXPORTS = [

@@ -9,14 +9,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbn256msm.so")
 SOURCES = ["bn256msm.hip"]
-HEADERS = ["fe29.cuh", "fr.cuh", "fe_mul_gen.inc", "g1.cuh", "kernels.cuh", "host_g1.h", os.path.join("..", "..", "include", "bn256msm.h")]
+
+
+def _headers() -> list:
+    """Everything the translation unit can include: csrc/*.h, *.cuh, *.inc and the public header."""
+    import glob
+    hs = []
+    for pat in ("*.h", "*.cuh", "*.inc"):
+        hs += glob.glob(os.path.join(CSRC, pat))
+    return hs + [os.path.join(HERE, "..", "include", "bn256msm.h")]
+
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

@@ -169,7 +169,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_PEER_A, WS_PEER_B, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -227,6 +227,13 @@ static void multi_bases_free(bn256_ctx* ctx, bn256_bases* b);
 static int multi_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, uint8_t* xy_be);
 static int multi_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars, bool on_device,
                      uint8_t out_xy_be[64]);
+static int multi_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n, const uint8_t* scalars_be,
+                                  int broadcast, bn256_bases** out);
+static int multi_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn256_bases* b, size_t boff, size_t n,
+                           bn256_bases** out);
+static int multi_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                       size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                       bn256_bases** out);
 
 static int ws_reserve(bn256_ctx* ctx, int which, size_t bytes) {
   if (ctx->cap[which] >= bytes) return BN256_OK;
@@ -494,11 +501,12 @@ static void normalize_into(bn256_ctx* ctx, const xyzz_mem* in, aff_mem* out, siz
 // holds bits 240..254 of a scalar below n/2, values <= 18395 of 2^19): its 2^20 digits per 2^20 points
 // would all land in the first 3.5 % of the buckets and make the sort's first groups three times as
 // large as the rest.  The top table level is therefore stored as (1 / s_i) * 2^(c (W-1)) * P_i and the top
-// digit multiplied by s_i = s - (i & 3), s = floor(2^(c-1) / 18395) = 28: the same sum, with the top
-// window's entries spread over the whole bucket range.  One s for every point would put them on every
-// 28th bucket only, 57 extra entries each: buckets three times the average, each across two or three
-// chunk boundaries of the accumulation, so that every wave of k_fix_boundary ran a chain of two additions
-// where most lanes have one.  Four scales hit four times as many buckets with a quarter each.
+// digit multiplied by s_i = s - (i & 7) (TOP_SCALES = 8, kernels.cuh), s = floor(2^(c-1) / 18396) = 28: the
+// same sum, with the top window's entries spread over the whole bucket range (18396 * 28 < 2^19).  One s
+// for every point would put them on every 28th bucket only, 57 extra entries each: buckets three times the
+// average, each across two or three chunk boundaries of the accumulation, so that every wave of
+// k_fix_boundary ran a chain of two additions where most lanes have one.  Eight scales hit eight times as
+// many buckets with an eighth each.
 // s = 1 (nothing changes) for every other window width.
 static u32 top_scale_for(int c) {
   if (c != 20) return 1;
@@ -1092,7 +1100,9 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
       MSM_MARK(1);
       hipLaunchKernelGGL(k_tile_scan, dim3(nblocks(nbt + 1, 256)), dim3(256), 0, s, hist, nsets, ntiles, nb, counts);
     } else {
-      // (bucket arrays beyond LDS, c >= 17 without the two-pass sort: never chosen by default)
+      // bucket arrays beyond LDS without the two-pass sort: a forced c >= 17, and by default every call of
+      // fewer than 2^15 points over a 20-bit-window table (a short sub-range of a big handle): global-atomic
+      // counting sort, then the fold over all 2^19 buckets -- ~0.3 ms of fixed cost, see DESIGN.md 4
       HIPCHK(hipMemsetAsync(heavy_count, 0, (first_pass ? HEAVY_WORDS : HEAVY_BASE) * sizeof(u32), s));
       HIPCHK(hipMemsetAsync(counts, 0, (nbt + 1) * 4, s));
       hipLaunchKernelGGL(k_recode<false>, dim3(nblocks(n_ch, 256)), dim3(256), 0, s, sc_ch, (u32)n_ch, (u32)c, (u32)W, nb,
@@ -1743,54 +1753,69 @@ static int fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32
   return BN256_OK;
 }
 
+// r[i] = s_i * in[i] (broadcast = 0) or s * in[i] (broadcast = 1) for i < n, normalised into the handle r;
+// enqueued on ctx's stream and waited for.  `in` is device memory of ctx's device.
+static int scalar_mul_into(bn256_ctx* ctx, const aff_mem* in, size_t n, const uint8_t* scalars_be, int broadcast,
+                           bn256_bases* r) {
+  if (!n) return BN256_OK;
+  int rc;
+  xyzz_mem* xs = nullptr;
+  if (broadcast) {
+    // one scalar for every point (vectorPointMulOnScalar): the uniform NAF chain of the fold kernel
+    static const uint8_t zero[32] = {0};
+    if ((rc = fold_points(ctx, in, in, 1u, scalars_be, zero, (u32)n, 0u, &xs))) return rc;
+  } else {
+    if ((rc = xyzz_scratch(ctx, n <= SCALAR_MUL_QUAD_MAX ? 2 * n : n, &xs))) return rc;
+    size_t sb = n * 32;
+    if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream));
+    if (n <= SCALAR_MUL_QUAD_MAX) {  // two GLV half-chains per point, then out[i] + phi(out[n + i])
+      hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, in,
+                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
+      hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
+    } else
+      hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, in,
+                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
+  }
+  normalize_into(ctx, xs, r->d, n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return BN256_OK;
+}
+
 extern "C" int bn256_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n,
                                       const uint8_t* scalars_be, int broadcast, bn256_bases** out) {
   if (!ctx || !in || !out || (!scalars_be && n)) return BN256_EINVAL;
-  SINGLE_DEVICE_ONLY(ctx);
+  if (ctx->nshard) return multi_scalar_mul_batch(ctx, in, off, n, scalars_be, broadcast, out);
   *out = nullptr;
   int rc = range_check(in, off, n);
   if (rc) return rc;
   HIPCHK(hipSetDevice(ctx->device));
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
-  xyzz_mem* xs = nullptr;
-  if (n && !broadcast && (rc = xyzz_scratch(ctx, n <= SCALAR_MUL_QUAD_MAX ? 2 * n : n, &xs))) { bn256_bases_free(ctx, r); return rc; }
-  if (n && broadcast) {
-    // one scalar for every point (vectorPointMulOnScalar): the uniform NAF chain of the fold kernel
-    static const uint8_t zero[32] = {0};
-    if ((rc = fold_points(ctx, (const aff_mem*)(in->d + off), (const aff_mem*)(in->d + off), 1u, scalars_be, zero, (u32)n,
-                          0u, &xs))) {
-      bn256_bases_free(ctx, r);
-      return rc;
-    }
-    normalize_into(ctx, xs, r->d, n);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
-  } else if (n) {
-    size_t sb = n * 32;
-    if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) { bn256_bases_free(ctx, r); return rc; }
-    hipError_t e = hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      if (n <= SCALAR_MUL_QUAD_MAX) {  // two GLV half-chains per point, then out[i] + phi(out[n + i])
-        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream,
-                           (const aff_mem*)(in->d + off), (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
-        hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
-      } else
-        hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(in->d + off),
-                           (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
-      normalize_into(ctx, xs, r->d, n);
-      e = hipStreamSynchronize(ctx->stream);
-    }
-    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+  if ((rc = scalar_mul_into(ctx, (const aff_mem*)(in->d + off), n, scalars_be, broadcast, r))) {
+    bn256_bases_free(ctx, r);
+    return rc;
   }
   *out = r;
+  return BN256_OK;
+}
+
+// r[i] = a[i] + b[i] for i < n (device memory of ctx's device), normalised into r; waited for
+static int add_into(bn256_ctx* ctx, const aff_mem* a, const aff_mem* b, size_t n, bn256_bases* r) {
+  if (!n) return BN256_OK;
+  xyzz_mem* xs;
+  int rc = xyzz_scratch(ctx, n, &xs);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_add_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, a, b, xs, (u32)n);
+  normalize_into(ctx, xs, r->d, n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return BN256_OK;
 }
 
 extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn256_bases* b, size_t boff,
                                size_t n, bn256_bases** out) {
   if (!ctx || !a || !b || !out) return BN256_EINVAL;
-  SINGLE_DEVICE_ONLY(ctx);
+  if (ctx->nshard) return multi_add_batch(ctx, a, aoff, b, boff, n, out);
   *out = nullptr;
   int rc = range_check(a, aoff, n);
   if (rc) return rc;
@@ -1798,14 +1823,9 @@ extern "C" int bn256_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff
   HIPCHK(hipSetDevice(ctx->device));
   bn256_bases* r = bases_alloc(n, 1, 0, &rc);
   if (!r) return rc;
-  if (n) {
-    xyzz_mem* xs;
-    if ((rc = xyzz_scratch(ctx, n, &xs))) { bn256_bases_free(ctx, r); return rc; }
-    hipLaunchKernelGGL(k_add_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)(a->d + aoff),
-                       (const aff_mem*)(b->d + boff), xs, (u32)n);
-    normalize_into(ctx, xs, r->d, n);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); bn256_bases_free(ctx, r); return BN256_EHIP; }
+  if ((rc = add_into(ctx, (const aff_mem*)(a->d + aoff), (const aff_mem*)(b->d + boff), n, r))) {
+    bn256_bases_free(ctx, r);
+    return rc;
   }
   *out = r;
   return BN256_OK;
@@ -1857,15 +1877,13 @@ extern "C" int bn256_com_batch(bn256_ctx* ctx, const uint8_t g_xy_be[64], const 
 
 // fold + normalisation into the handle r (max(n_lo, n_hi) points) on `on`'s stream and scratch; the
 // caller synchronises
-static int fold2_into(bn256_ctx* on, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
-                      size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
-                      bn256_bases* r) {
+static int fold2_into(bn256_ctx* on, const aff_mem* lo, size_t n_lo, const aff_mem* hi, size_t n_hi, size_t stride,
+                      const uint8_t s_lo_be[32], const uint8_t s_hi_be[32], bn256_bases* r) {
   size_t n = std::max(n_lo, n_hi);
   HIPCHK(hipSetDevice(on->device));
   if (n) {
     xyzz_mem* xs;
-    int rc = fold_points(on, (const aff_mem*)(lo->d + lo_off), (const aff_mem*)(hi->d + hi_off), (u32)stride, s_lo_be,
-                         s_hi_be, (u32)n_lo, (u32)n_hi, &xs);
+    int rc = fold_points(on, lo, hi, (u32)stride, s_lo_be, s_hi_be, (u32)n_lo, (u32)n_hi, &xs);
     if (rc) return rc;
     normalize_into(on, xs, r->d, n);
   }
@@ -1881,7 +1899,8 @@ static int fold2_enqueue(bn256_ctx* on, const bn256_bases* lo, size_t lo_off, si
   HIPCHK(hipSetDevice(on->device));
   bn256_bases* r = bases_alloc(std::max(n_lo, n_hi), 1, 0, &rc);
   if (!r) return rc;
-  if ((rc = fold2_into(on, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, r))) {
+  if ((rc = fold2_into(on, (const aff_mem*)(lo->d + lo_off), n_lo, (const aff_mem*)(hi->d + hi_off), n_hi, stride, s_lo_be,
+                       s_hi_be, r))) {
     bn256_bases_free(on, r);
     return rc;
   }
@@ -1893,7 +1912,7 @@ extern "C" int bn256_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off,
                            size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32],
                            const uint8_t s_hi_be[32], bn256_bases** out) {
   if (!ctx || !lo || !hi || !out || !s_lo_be || !s_hi_be || stride == 0) return BN256_EINVAL;
-  SINGLE_DEVICE_ONLY(ctx);
+  if (ctx->nshard) return multi_fold2(ctx, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, out);
   int rc = fold2_enqueue(ctx, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, s_lo_be, s_hi_be, out);
   if (rc) return rc;
   hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -1926,7 +1945,8 @@ extern "C" int bn256_fold2_submit(bn256_ctx* ctx, const bn256_bases* lo, size_t 
   memcpy(sc.lo, s_lo_be, 32);
   memcpy(sc.hi, s_hi_be, 32);
   rc = lane_start(ctx, l, true, [=](bn256_ctx* lane, lane_ticket*) -> int {
-    int rc2 = fold2_into(lane, lo, lo_off, n_lo, hi, hi_off, n_hi, stride, sc.lo, sc.hi, r);
+    int rc2 = fold2_into(lane, (const aff_mem*)(lo->d + lo_off), n_lo, (const aff_mem*)(hi->d + hi_off), n_hi, stride, sc.lo,
+                         sc.hi, r);
     if (rc2) return rc2;
     hipError_t e = hipStreamSynchronize(lane->stream);
     if (e != hipSuccess) {
@@ -2533,6 +2553,14 @@ static int multi_bases_download(bn256_ctx* ctx, const bn256_bases* b, size_t off
   return BN256_OK;
 }
 
+// BN256_FORCE_PEER_COPY=1 (environment): every cross-shard operand takes the hipMemcpyPeerAsync
+// path even when source and destination are the same device -- lets a one-GPU box (devices = {0, 0}) run
+// the code an 8-GPU node runs (tests/test_gpu_multi_device_ctx.py)
+static bool force_peer_copy() {  // read at every call: a test switches it on and off inside one process
+  const char* e = getenv("BN256_FORCE_PEER_COPY");
+  return e && atoi(e) != 0;
+}
+
 // scalars: host memory, or (on_device) memory of any one GPU -- a shard on another device copies its
 // slice over the peer link first
 static int multi_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const uint8_t* scalars, bool on_device,
@@ -2554,7 +2582,7 @@ static int multi_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n,
     const size_t m = hi - lo, loc = lo - b->shard_off[s];
     const uint8_t* src = scalars + 32 * (lo - off);
     if (!on_device) return bn256_msm(c, b->shard[s], loc, m, src, parts[s]);
-    if (src_dev == c->device) return bn256_msm_dev(c, b->shard[s], loc, m, src, parts[s]);
+    if (src_dev == c->device && !force_peer_copy()) return bn256_msm_dev(c, b->shard[s], loc, m, src, parts[s]);
     HIPCHK(hipSetDevice(c->device));
     int r = ws_reserve(c, WS_SCALARS, m * 32);
     if (r) return r;
@@ -2563,4 +2591,132 @@ static int multi_msm(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n,
   });
   if (rc) return rc;
   return bn256_g1_sum(&parts[0][0], (size_t)ctx->nshard, out_xy_be);
+}
+
+// ---- element-wise entry points on a multi-device context ("the batched fold / scalar-mul
+// kernels are element-wise and shard the same way with no collective").  The OUTPUT handle is sharded evenly
+// (the slices bn256_bases_upload would make); shard s computes its slice on its own device with the
+// single-device kernels.  An operand range that one shard on that device holds is read in place; anything
+// else -- the IPA fold's lo / hi halves live on different GPUs (go/bp/main.go:355-356) -- is copied piece by
+// piece over the peer link into a workspace of the computing shard (point-to-point hipMemcpyPeerAsync on the
+// shard's own stream; no collective).  WNLA's even / odd fold (go/bppp/docs_test.go:1325-1326) and
+// vectorPointMulOnScalar / hadamardPointMul over whole vectors stay local.
+static bn256_bases* multi_out_alloc(bn256_ctx* ctx, size_t n) {
+  bn256_bases* r = new (std::nothrow) bn256_bases();
+  if (!r) return nullptr;
+  r->n = n;
+  r->levels = 1;
+  r->top_scale = 1;
+  r->nshard = ctx->nshard;
+  const size_t base = n / ctx->nshard, rem = n % ctx->nshard;
+  for (int s = 0; s <= ctx->nshard; s++) r->shard_off[s] = (size_t)s * base + std::min<size_t>((size_t)s, rem);
+  return r;
+}
+// level 0 of [start, start + span) of a sharded handle as memory of shard context c's device
+static int shard_view(bn256_ctx* c, const bn256_bases* b, size_t start, size_t span, int which, const aff_mem** out) {
+  *out = nullptr;
+  if (!span) return BN256_OK;
+  if (!force_peer_copy())
+    for (int t = 0; t < b->nshard; t++)
+      if (b->shard[t]->dev == c->device && start >= b->shard_off[t] && start + span <= b->shard_off[t + 1]) {
+        *out = b->shard[t]->d + (start - b->shard_off[t]);
+        return BN256_OK;
+      }
+  int rc = ws_reserve(c, which, span * sizeof(aff_mem));
+  if (rc) return rc;
+  aff_mem* dst = (aff_mem*)c->ws[which];
+  for (int t = 0; t < b->nshard; t++) {
+    const size_t lo = std::max(start, b->shard_off[t]), hi = std::min(start + span, b->shard_off[t + 1]);
+    if (lo >= hi) continue;
+    HIPCHK(hipMemcpyPeerAsync(dst + (lo - start), c->device, b->shard[t]->d + (lo - b->shard_off[t]), b->shard[t]->dev,
+                              (hi - lo) * sizeof(aff_mem), c->stream));
+  }
+  *out = dst;
+  return BN256_OK;
+}
+static int multi_check(const bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, size_t stride) {
+  if (!b->nshard || b->nshard != ctx->nshard) return BN256_EINVAL;  // handle and context must be of one kind
+  if (stride == 0) return BN256_EINVAL;
+  if (off > b->n) return BN256_ELENGTH;
+  if (n == 0) return BN256_OK;
+  const size_t avail = b->n - off;
+  if (avail == 0 || (n - 1) > (avail - 1) / stride) return BN256_ELENGTH;
+  return BN256_OK;
+}
+// runs fn(s, shard context, first output index, count, output handle of the shard) on every shard
+template <class F>
+static int multi_elementwise(bn256_ctx* ctx, size_t n, bn256_bases** out, F fn) {
+  *out = nullptr;
+  if (n >= (1ull << 31)) return BN256_ETOOLARGE;
+  bn256_bases* r = multi_out_alloc(ctx, n);
+  if (!r) return BN256_ENOMEM;
+  int rc = for_each_shard(ctx->nshard, [&](int s) -> int {
+    bn256_ctx* c = ctx->shard[s];
+    HIPCHK(hipSetDevice(c->device));
+    const size_t i0 = r->shard_off[s], m = r->shard_off[s + 1] - i0;
+    int rc2;
+    if (!(r->shard[s] = bases_alloc(m, 1, 0, &rc2))) return rc2;
+    if (!m) return BN256_OK;
+    rc2 = fn(s, c, i0, m, r->shard[s]);
+    if (rc2) (void)hipStreamSynchronize(c->stream);  // nothing enqueued may outlive a failed call
+    return rc2;
+  });
+  if (rc) {
+    for (int s = 0; s < r->nshard; s++)
+      if (r->shard[s]) bn256_bases_free(ctx->shard[s], r->shard[s]);
+    delete r;
+    return rc;
+  }
+  *out = r;
+  return BN256_OK;
+}
+
+static int multi_scalar_mul_batch(bn256_ctx* ctx, const bn256_bases* in, size_t off, size_t n, const uint8_t* scalars_be,
+                                  int broadcast, bn256_bases** out) {
+  *out = nullptr;
+  int rc = multi_check(ctx, in, off, n, 1);
+  if (rc) return rc;
+  return multi_elementwise(ctx, n, out, [&](int, bn256_ctx* c, size_t i0, size_t m, bn256_bases* r) -> int {
+    const aff_mem* src;
+    int rc2 = shard_view(c, in, off + i0, m, WS_PEER_A, &src);
+    if (rc2) return rc2;
+    return scalar_mul_into(c, src, m, broadcast ? scalars_be : scalars_be + 32 * i0, broadcast, r);
+  });
+}
+
+static int multi_add_batch(bn256_ctx* ctx, const bn256_bases* a, size_t aoff, const bn256_bases* b, size_t boff, size_t n,
+                           bn256_bases** out) {
+  *out = nullptr;
+  int rc;
+  if ((rc = multi_check(ctx, a, aoff, n, 1)) || (rc = multi_check(ctx, b, boff, n, 1))) return rc;
+  return multi_elementwise(ctx, n, out, [&](int, bn256_ctx* c, size_t i0, size_t m, bn256_bases* r) -> int {
+    const aff_mem *pa, *pb;
+    int rc2;
+    if ((rc2 = shard_view(c, a, aoff + i0, m, WS_PEER_A, &pa)) || (rc2 = shard_view(c, b, boff + i0, m, WS_PEER_B, &pb)))
+      return rc2;
+    return add_into(c, pa, pb, m, r);
+  });
+}
+
+static int multi_fold2(bn256_ctx* ctx, const bn256_bases* lo, size_t lo_off, size_t n_lo, const bn256_bases* hi,
+                       size_t hi_off, size_t n_hi, size_t stride, const uint8_t s_lo_be[32], const uint8_t s_hi_be[32],
+                       bn256_bases** out) {
+  *out = nullptr;
+  int rc;
+  if ((rc = multi_check(ctx, lo, lo_off, n_lo, stride)) || (rc = multi_check(ctx, hi, hi_off, n_hi, stride))) return rc;
+  return multi_elementwise(ctx, std::max(n_lo, n_hi), out,
+                           [&](int, bn256_ctx* c, size_t i0, size_t m, bn256_bases* r) -> int {
+    // this slice's share of either side (a side that has run out counts as infinity: vectorPointsAdd's padding)
+    const size_t m_lo = i0 < n_lo ? std::min(m, n_lo - i0) : 0, m_hi = i0 < n_hi ? std::min(m, n_hi - i0) : 0;
+    const aff_mem *pl = nullptr, *ph = nullptr;
+    int rc2;
+    if ((rc2 = shard_view(c, lo, lo_off + i0 * stride, m_lo ? (m_lo - 1) * stride + 1 : 0, WS_PEER_A, &pl)) ||
+        (rc2 = shard_view(c, hi, hi_off + i0 * stride, m_hi ? (m_hi - 1) * stride + 1 : 0, WS_PEER_B, &ph)))
+      return rc2;
+    if (!pl) pl = ph;  // never read (n = 0 on that side), but the kernels want a valid pointer
+    if (!ph) ph = pl;
+    if ((rc2 = fold2_into(c, pl, m_lo, ph, m_hi, stride, s_lo_be, s_hi_be, r))) return rc2;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return BN256_OK;
+  });
 }

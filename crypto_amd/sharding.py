@@ -34,9 +34,12 @@ class _Exchange:
         self.on_gpu = on_gpu
 
     def run(self, part: bytes) -> list[bytes]:
+        """Blocking exchange of ONE point per rank (slot 0 of the batch; the other slots travel unused)."""
         import torch
         import torch.distributed as dist
-        self.h_in.numpy()[:] = memoryview(part)
+        if len(part) != 64:
+            raise ValueError("a marshalled G1 point is 64 bytes")
+        self.h_in.numpy()[:64] = memoryview(part)
         if self.on_gpu:
             self.d_in.copy_(self.h_in, non_blocking=True)
         dist.all_gather_into_tensor(self.d_out, self.d_in)

@@ -12,8 +12,9 @@
  * Conventions: every entry point returns 0 or a negative BN256_E* code and never aborts
  * or throws.  Output buffers are caller-allocated; handles are library-owned and freed
  * explicitly; no caller pointer is retained after return (cgo rule).  A context is used
- * from one thread at a time; distinct contexts are independent.  One context = one GPU
- * (one process per GPU; partial sums of a sharded MSM are combined with bn256_g1_sum).
+ * from one thread at a time; distinct contexts are independent.  A context is one GPU
+ * (bn256_ctx_create: one process per GPU, partial sums of a sharded MSM are combined with
+ * bn256_g1_sum) or 1..8 GPUs of the node behind the same calls (bn256_ctx_create_multi).
  */
 #ifndef BN256MSM_H
 #define BN256MSM_H
@@ -54,11 +55,19 @@ void bn256_ctx_destroy(bn256_ctx* ctx);
  * pipeline side by side and add the <= 8 partial points on the host, so vectorPointScalarMul
  * (go/bp/util.go:165-175) uses the node through the same call.  Host scalars go to each device over
  * its own PCIe link; a device pointer may live on any one GPU (the other shards copy their slices
- * over the peer link).  Fr vectors, bn256_random_scalars and bn256_selftest of such a context live on
- * devices[0]; bn256_bases_free / _len / _download, bn256_ctx_set_tuning and bn256_last_timing (slowest
- * shard) work as usual; every other entry point returns BN256_ENOTSUP (the element-wise kernels
- * shard trivially but are not wired up).  The process-per-GPU form (bench.py, RCCL all_gather of the
- * partials + bn256_g1_sum) needs nothing of this. */
+ * over the peer link).  The element-wise calls -- bn256_scalar_mul_batch, bn256_add_batch, bn256_fold,
+ * bn256_fold2 (vectorPointMulOnScalar, the h1 loop, hadamardPointMul, the generator folds:
+ * go/bp/util.go:177-195, go/bp/main.go:156-159,355-356, go/bppp/docs_test.go:1325-1326) -- return a
+ * handle sharded evenly like an uploaded one; every shard computes its slice on its own device, reads
+ * an operand range in place when one of its device's shards holds it and copies it over the peer link
+ * otherwise (the IPA fold's lo / hi halves live on different GPUs; WNLA's even / odd fold and whole-vector
+ * calls stay local): point-to-point copies, no collective.  Fr vectors, bn256_random_scalars and
+ * bn256_selftest of such a context live on devices[0]; bn256_bases_free / _len / _download,
+ * bn256_ctx_set_tuning and bn256_last_timing (slowest shard) work as usual; the remaining entry points
+ * (multi-segment MSMs, the submit / wait pairs, bn256_com_batch, Fr kernels on strided views,
+ * bn256_msm_dev_noalloc) return BN256_ENOTSUP.  BN256_FORCE_PEER_COPY=1 in the environment makes every
+ * cross-shard operand take the peer-copy path even between shards of one device (test switch).  The
+ * process-per-GPU form (bench.py, RCCL all_gather of the partials + bn256_g1_sum) needs nothing of this. */
 #define BN256_MAX_DEVICES 8
 int bn256_ctx_create_multi(const int* devices, int ndev, bn256_ctx** out);
 /* The HIP stream (hipStream_t) every kernel of this context is launched on. */
@@ -89,20 +98,28 @@ int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, co
  * stream produced the scalars (torch's current stream, say), the caller synchronises that stream or
  * event before the call. */
 
-/* bn256_msm_dev for callers that cannot call hipMalloc: code under HIP graph capture, tight serving
- * loops, harnesses that forbid allocation.  It has NO counterpart in the reference (whose
+/* bn256_msm_dev for callers that cannot call hipMalloc: tight serving loops, harnesses that forbid
+ * allocation, code that must not touch the allocator between two points of a HIP graph capture (the
+ * call itself is NOT capturable: it synchronises its stream and finishes on the host).  It has NO
+ * counterpart in the reference (whose
  * vectorPointScalarMul, go/bp/util.go:165-175, allocates freely on the Go heap); same arguments, same
  * result bytes as bn256_msm_dev.  The call makes no hipMalloc / hipFree / hipHostMalloc and no other
  * allocating library call: the pipeline's workspaces (sort records, bucket offsets, bucket and partial
  * sums, packed results) are carved from a file-scope __device__ array of BN256_NOALLOC_SCRATCH_BYTES
  * that every GPU the library runs on holds until the process ends; its device address is resolved once
  * per device by bn256_ctx_create.  A call whose workspaces do not fit returns BN256_ESCRATCH before
- * anything is enqueued: the 384 MiB hold a fixed-base (BN256_PRECOMPUTE) call of up to 2^20 points
- * (342 MiB with the split-sort workspace that skewed scalars need) and a table-less call of up to
- * 2^20.  All contexts on one GPU share that GPU's array and it keeps the last call's contents (the
+ * anything is enqueued: the default 352 MiB hold a fixed-base (BN256_PRECOMPUTE) call of up to 2^20
+ * points (278 MiB; 342 MiB with the split-sort workspace that skewed scalars need) and a table-less call
+ * of up to 2^20 (290 MiB) -- the largest calls the entry point is meant for.  STANDING COST: the array is
+ * part of the library's code object, so EVERY process that loads the library holds it on EVERY GPU it
+ * touches, whether or not this entry point is ever called; a deployment that never calls it builds with
+ * -DBN256_NOALLOC_SCRATCH_BYTES=256 (every call then returns BN256_ESCRATCH), one that needs larger
+ * calls with a larger value.  All contexts on one GPU share that GPU's array and it keeps the last call's contents (the
  * pipeline initialises what it reads): calls that overlap on one GPU -- two contexts, two threads --
  * race; serialise them.  The other entry points are unaffected. */
-#define BN256_NOALLOC_SCRATCH_BYTES ((size_t)384 << 20)
+#ifndef BN256_NOALLOC_SCRATCH_BYTES
+#define BN256_NOALLOC_SCRATCH_BYTES ((size_t)352 << 20)
+#endif
 int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                           uint8_t out_xy_be[64]);
 
