@@ -117,8 +117,9 @@ def _elementwise_round(e, orc, n):
     per-point loops; then an MSM over a result handle (the next IPA level's commitment)."""
     import ctypes as C
     braw = bytearray(orc.synth_bases(SEED_B, n))
-    braw[64 * 5:64 * 6] = bytes(64)                           # an infinity point
-    braw[64 * (n - 2):64 * (n - 1)] = braw[64 * 1:64 * 2]     # duplicates across the shard boundary
+    if n > 16:
+        braw[64 * 5:64 * 6] = bytes(64)                       # an infinity point
+        braw[64 * (n - 2):64 * (n - 1)] = braw[64 * 1:64 * 2]  # duplicates across the shard boundary
     braw = bytes(braw)
     sraw = orc.synth_scalars(SEED_S, n)
     k, k2 = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF, (1 << 255) + 12345
