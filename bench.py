@@ -29,7 +29,13 @@ and their calls do not overlap (tools/probe/stream_probe.hip).
 Besides `value` the line carries, measured in the same run: `single_call` (SURVEY 8d's wording of
 the metric: one blocking call, median), `pcie_inclusive` (scalars in host memory, never `value`),
 `bulletproofs_like` (the aL / aR scalar distribution), `n_2p24` (2^24 points on this one GPU) at
-N = 1, and `strong_2p24` (2^24 points over all ranks) at N > 1.
+N = 1, and `strong_2p24` (2^24 points over all ranks, with the same job on rank 0's GPU alone beside it:
+`efficiency_vs_n1`) at N > 1.  At N = 1 also the other BASELINE.json configs and the element-wise rows, each
+a median of >= 5 runs after a warm one, each with its exactness flag: `no_table_2p20` (the reference's loop
+has no precomputation), `bp_n64` (configs[0]: go/bp prove / verify), `bppp_2p20` (configs[3]: four BP++
+commitments + the WNLA at |l| = 2^20), `h1_2p20`, `fold_2p19` (go/bp/main.go:156-159, :355-356).
+At N > 1 the line proves what took part: `ranks` holds world size, every rank's device (PCI bus id, UUID),
+and each rank's k_accumulate time.
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for the roofline accounting.
 """
@@ -88,15 +94,46 @@ def cpu_baseline(sample_terms: int):
     return sample_terms / dt, orc
 
 
-def cpu_model() -> str:
+def cpu_model() -> dict:
+    """What the box says about its host CPU (a KVM guest here: the model string may be masked to "AMD EPYC",
+    so family / model / stepping are reported beside it) and how many cores this process may use."""
+    info = {}
     try:
         with open("/proc/cpuinfo") as f:
             for ln in f:
-                if ln.startswith("model name"):
-                    return ln.split(":", 1)[1].strip()
+                k, _, v = ln.partition(":")
+                k = k.strip()
+                if k in ("model name", "cpu family", "model", "stepping", "cpu MHz") and k not in info:
+                    info[k] = v.strip()
+                if not ln.strip():
+                    break
     except OSError:
         pass
-    return "unknown"
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
+    return {"model_name": info.get("model name", "unknown"), "cpu_family": info.get("cpu family"),
+            "model": info.get("model"), "stepping": info.get("stepping"), "cpu_mhz": info.get("cpu MHz"),
+            "os_cpu_count": os.cpu_count(), "usable_cpus": usable, "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS")}
+
+
+def cpu_baseline_all_cores(orc, sample_terms: int):
+    """the same per-term loop split over the host's cores (OpenMP in the C restatement; the
+    chunks' partial sums are added at the end).  Not the reference (which is one goroutine)."""
+    try:
+        threads = C.CDLL("libgomp.so.1").omp_get_max_threads()
+    except OSError:
+        threads = None
+    bases = orc.synth_bases(SEED_BASES, sample_terms)
+    scalars = orc.synth_scalars(SEED_SCALARS, sample_terms)
+    t0 = time.perf_counter()
+    r = orc.msm(bases, scalars, mt=True)
+    dt = time.perf_counter() - t0
+    return {"value": sample_terms / dt, "unit": "points/s", "cores": threads, "kind": "port",
+            "label": "same algorithm on all host cores (OpenMP, 64 chunks) -- NOT the reference, which is single-goroutine",
+            "sample": f"first {sample_terms} terms of the same seeded workload, {dt:.1f} s",
+            "matches_closed_form": bool(r == orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, sample_terms))}
 
 
 def launcher(args) -> int:
@@ -229,6 +266,25 @@ def worker(args) -> int:
     eng.set_phase_timing(False)
     sync()
 
+    # who took part (N > 1 or the forced 1-rank rehearsal): every rank's device and its k_accumulate time,
+    # all-gathered, so that the line itself shows that `world` DISTINCT GPUs ran the job
+    ranks_info = None
+    if use_dist:
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_name": prop.name,
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                                  getattr(prop, "pci_device_id", 0)),
+                "uuid": str(getattr(prop, "uuid", "")), "points": wl.n,
+                "k_accumulate_ms": phase[3] / nblk, "single_call_median_ms": statistics.median(per_call) * 1e3,
+                "hostname": os.uname().nodename, "pid": os.getpid()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        acc_ms = [g["k_accumulate_ms"] for g in gathered]
+        ids = {(g["hostname"], g["pci_bus_id"], g["uuid"]) for g in gathered}
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "distinct_devices": len(ids), "all_distinct": len(ids) == world,
+                      "k_accumulate_ms_min": min(acc_ms), "k_accumulate_ms_max": max(acc_ms), "per_rank": gathered}
+
     line = None
     if rank == 0:
         traffic = executed = pmc_file = None
@@ -284,6 +340,7 @@ def worker(args) -> int:
             "phases_ms": {"sort_pass_a": phase[0], "scan": phase[1], "sort_pass_b": phase[2], "accumulate": phase[3],
                           "fix": phase[4], "reduce": phase[5], "device_total": phase[6]},
             "host_us_per_step": {"submit": host_timed[0], "wait": host_timed[1], "exchange": host_timed[2]},
+            "ranks": ranks_info,
             # SURVEY 8(d)'s wording of the metric: N / wall time of ONE blocking call (result download and,
             # at N > 1, exchange included; scalars resident), median of >= 10 after 2 warm-ups
             "single_call": {"calls": nblk, "median_ms": med * 1e3, "mean_ms": dt_blocking / nblk * 1e3,
@@ -332,6 +389,7 @@ def worker(args) -> int:
             "value": v, "unit": "points/s", "cores": 1, "kind": "port",
             "device_result_matches_oracle_closed_form": bool(exact == result),
             "host_cpu": cpu_model(),
+            "all_cores": cpu_baseline_all_cores(orc, 4 * args.cpu_sample),
             # the algorithm is O(N): seconds for the full sizes from the sampled rate (extrapolated, not measured)
             "extrapolated_seconds": {"2^20": (1 << 20) / v, "2^24": (1 << 24) / v},
             "sample": f"first {args.cpu_sample} terms of the same seeded workload, reference algorithm "
@@ -339,8 +397,9 @@ def worker(args) -> int:
         }
 
     if not args.no_extras and not strong and not args.no_precompute:
-        if world == 1:
+        if world == 1 and not use_dist:
             line.update(extras_one_gpu(eng, wl, orc, dev, torch))
+            line.update(extras_prover(eng, wl, orc, dev, torch, result))
         # 2^24 points in all (configs[4]'s job): on this GPU at N = 1, sliced over the ranks at N > 1
         wl.free()
         big = Workload(1 << 24, True)
@@ -364,6 +423,39 @@ def worker(args) -> int:
                 entry["matches_oracle_closed_form"] = bool(orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, 1 << 24) == resb)
             line["n_2p24" if world == 1 else "strong_2p24"] = entry
         big.free()
+        if world > 1:
+            # the same 2^24-point job on rank 0's GPU alone, in this very run (the other ranks' GPUs idle, their
+            # processes parked on the rendezvous store): the N = 1 figure the scaling efficiency is taken against
+            if rank == 0:
+                t0 = time.perf_counter()
+                b1 = eng.random_bases(SEED_BASES, 1 << 24, flags=flags)
+                setup1 = time.perf_counter() - t0
+                s1 = torch.empty((1 << 24) * 32, dtype=torch.uint8, device=dev)
+                eng.random_scalars_into(SEED_SCALARS, 1 << 24, s1.data_ptr())
+                sub1 = lambda: eng.msm_submit(b1, s1.data_ptr(), 1 << 24)  # noqa: E731
+                sharding.run_pipelined(2, args.depth, sub1, eng.msm_wait)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res1 = sharding.run_pipelined(ksteps, args.depth, sub1, eng.msm_wait)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t0
+                e = line["strong_2p24"]
+                e["n1_same_run"] = {"ms_per_step": dt1 / ksteps * 1e3, "points_per_s": (1 << 24) * ksteps / dt1,
+                                    "setup_seconds_bases": setup1, "same_result": bool(res1 == resb)}
+                e["speedup_vs_n1"] = (dt1 / ksteps) / (dtb / ksteps)
+                e["efficiency_vs_n1"] = e["speedup_vs_n1"] / world
+                b1.free()
+                s1 = None
+            try:
+                from datetime import timedelta
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set("bn256_n1_ref_done", "1")
+                else:
+                    store.wait(["bn256_n1_ref_done"], timedelta(seconds=400))
+            except Exception:  # noqa: BLE001 -- private accessor: fall back to the collective
+                pass
+            dist.barrier()
         # the other form of multi-GPU use: ONE context over all the devices behind the C ABI, one process
         # (tools/multi_ctx_bench.py, a child of rank 0; the ranks wait at the barrier with their memory freed)
         if use_dist:
@@ -464,6 +556,172 @@ def extras_one_gpu(eng, wl, orc, dev, torch) -> dict:
     if orc is not None:
         out["bulletproofs_like"]["matches_oracle_closed_form"] = bool(
             orc.synth_msm_closed_form_scalars(SEED_BASES, arr.tobytes()) == r_bp)
+    return out
+
+
+def load_pmc(kernel_prefix: str):
+    """Per-launch counter means of a kernel from the newest committed element-wise PMC pass, or None."""
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_elementwise.json")))[-1]
+        with open(f) as fh:
+            d = json.load(fh)
+        for k, v in d.items():
+            if k.startswith(kernel_prefix):
+                return v, os.path.relpath(f, ROOT)
+    except Exception:  # noqa: BLE001
+        pass
+    return None, None
+
+
+# Canonical work of ONE scalar multiplication for the element-wise rows (the MSM's 23 120 has no meaning there):
+# the reference's own GLV double-and-add as SURVEY 3.5 states it -- 128 doublings (6M + 3S = 9 modmul) and 96
+# mixed additions (8M + 2S = 10) -- at SURVEY 8(d)'s 136 IMAD per modmul: (128 * 9 + 96 * 10) * 136.
+IMAD_PER_SCALAR_MUL = (128 * 9 + 96 * 10) * 136
+
+
+def extras_prover(eng, wl, orc, dev, torch, result) -> dict:
+    """N = 1: the table-less MSM, configs[0] (go/bp N = 64), configs[3] (BP++ commitments + WNLA at 2^20) and
+    the element-wise rows.  Median of >= 5 after one warm run; every leg carries its exactness flag."""
+    import crypto_amd
+    from crypto_amd import bp as bpm
+    n = wl.n
+    out = {}
+
+    def med_of(fn, reps=5, warm=1):
+        for _ in range(warm):
+            r = fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), r
+
+    # ---- the reference's loop has no precomputation (go/bp/util.go:165-175), and every IPA / WNLA round after
+    # the first runs over folded generators: one blocking bn256_msm_dev over a handle WITHOUT a table
+    plain = eng.random_bases(SEED_BASES, n, first=wl.first)
+    t, r = med_of(lambda: eng.msm_dev(plain, wl.scalars.data_ptr(), n), reps=7)
+    out["no_table_2p20"] = {"median_ms": t * 1e3, "points_per_s": n / t, "calls": 7,
+                            "whole_msm_frac": (n * IMAD_PER_POINT / t) / IMAD_PEAK,
+                            "same_result_as_fixed_base": bool(r == result),
+                            "note": "blocking bn256_msm_dev, 16 windows of 16 bits, 16 bucket sets, scalars resident"}
+    # ---- element-wise rows on the same 2^n points: h1[i] = yinvn[i] * H[i] (go/bp/main.go:156-159) through
+    # bn256_scalar_mul_batch(broadcast = 0) with the scalars in pinned host memory (the upload is part of the
+    # call), and the generator fold g' = x^-1 G_lo + x G_hi (go/bp/main.go:355-356) through bn256_fold
+    if orc is not None:
+        host_sc = wl.scalars.cpu().pin_memory()
+        sraw = host_sc.numpy().tobytes()
+        kraw = orc.synth_base_scalars(SEED_BASES, n, wl.first)
+        sc = lambda i: int.from_bytes(sraw[32 * i:32 * i + 32], "big")  # noqa: E731
+        kk = lambda i: int.from_bytes(kraw[32 * i:32 * i + 32], "big")  # noqa: E731
+
+        def h1():
+            h = C.c_void_p()
+            eng._chk(eng.lib.bn256_scalar_mul_batch(eng.ctx, plain.h, 0, n, C.cast(C.c_void_p(host_sc.data_ptr()), C.c_char_p),
+                                                    0, C.byref(h)))
+            return crypto_amd.engine.Bases(eng, h)
+
+        def timed_handles(fn, reps=5):
+            fn().free()
+            ts, r = [], None
+            for _ in range(reps):
+                if r is not None:
+                    r.free()
+                t0 = time.perf_counter()
+                r = fn()
+                ts.append(time.perf_counter() - t0)
+            return statistics.median(ts), r
+
+        t, r = timed_handles(h1)
+        idx = [0, 1, n // 3, n - 1]
+        ok = all(r.download(i, 1)[0] == orc.g0_mul(sc(i) * kk(i) % N_ORDER) for i in idx)
+        r.free()
+        pmc, src = load_pmc("k_scalar_mul")
+        out["h1_2p20"] = {"median_ms": t * 1e3, "points_per_s": n / t, "calls": 5, "sampled_outputs_match_closed_form": bool(ok),
+                          "canonical_imad_per_point": IMAD_PER_SCALAR_MUL,
+                          "imad_issue_frac": (n * IMAD_PER_SCALAR_MUL / t) / IMAD_PEAK,
+                          "executed_valu_lane_ops_per_point": (pmc["SQ_INSTS_VALU"] * 64.0 / n) if pmc else None,
+                          "pmc_source": src,
+                          "note": "bn256_scalar_mul_batch(broadcast=0), 32 MiB of scalars uploaded from pinned memory inside the call"}
+        s_lo, s_hi = (0x1234567 << 200) | 99, N_ORDER - 0xabcdef123
+        half = n // 2
+        t, r = timed_handles(lambda: eng.fold(plain, 0, plain, half, half, s_lo, s_hi))
+        ok = all(r.download(i, 1)[0] == orc.g0_mul((s_lo * kk(i) + s_hi * kk(i + half)) % N_ORDER) for i in (0, 7, half // 2, half - 1))
+        r.free()
+        pmc, src = load_pmc("k_fold_points")
+        out["fold_2p19"] = {"median_ms": t * 1e3, "outputs_per_s": half / t, "calls": 5, "sampled_outputs_match_closed_form": bool(ok),
+                            "canonical_imad_per_output": 2 * IMAD_PER_SCALAR_MUL + 14 * 136,
+                            "imad_issue_frac": (half * (2 * IMAD_PER_SCALAR_MUL + 14 * 136) / t) / IMAD_PEAK,
+                            "executed_valu_lane_ops_per_output": (pmc["SQ_INSTS_VALU"] * 64.0 / half) if pmc else None,
+                            "pmc_source": src,
+                            "note": "bn256_fold over the two halves of a 2^20-point vector: 2^19 outputs s_lo*lo_i + s_hi*hi_i"}
+        host_sc = None
+    plain.free()
+    # ---- configs[0]: go/bp 64-bit range proof, prove + verify (go/bp/main_test.go:16-36) through the C++ mirror,
+    # product entry points (OS randomness; generators resident)
+    pub = bpm.BulletProofPublic(eng, 64)
+    v, prv = 987654321, 0x1234567890ABCDEF
+    pub.verify(pub.prove(v, prv))
+    tp, tv, acc = [], [], True
+    for _ in range(5):
+        t0 = time.perf_counter()
+        pr = pub.prove(v, prv)
+        t1 = time.perf_counter()
+        err = pub.verify(pr)
+        t2 = time.perf_counter()
+        tp.append(t1 - t0)
+        tv.append(t2 - t1)
+        acc = acc and err is None
+    tampered = bytearray(pr)
+    tampered[64 * 5 + 31] ^= 1  # tx
+    out["bp_n64"] = {"prove_median_ms": statistics.median(tp) * 1e3, "verify_median_ms": statistics.median(tv) * 1e3,
+                     "runs": 5, "verify_accepts": bool(acc), "tampered_rejected": pub.verify(bytes(tampered)) is not None,
+                     "proof_bytes": len(pr), "config": "BASELINE.json configs[0]: go/bp range proof N = 64 (bp_prove / bp_verify)"}
+    pub.G.free()
+    pub.H.free()
+    # ---- configs[3]: the four BP++ vector commitments Co, Cl, Cr, Cs (go/bppp/docs_test.go:560-564,588-589,
+    # 1002-1003) at Nv = Nm = 2^20, each <HVec, r||l> + <GVec, n> as one pipeline over two fixed-base tables
+    nv = nm = 1 << 20
+    SEED_H, SEED_G = 0xB9901, 0xB9902
+    t0 = time.perf_counter()
+    H = eng.random_bases(SEED_H, 9 + nv, flags=crypto_amd.PRECOMPUTE)
+    G = eng.random_bases(SEED_G, nm, flags=crypto_amd.PRECOMPUTE)
+    setup_ms = (time.perf_counter() - t0) * 1e3
+    seeds = [(0x21, 0x22), (0x23, 0x24), (0x25, 0x26), (0x27, 0x28)]
+    vec = [(eng.fr_random(a, 9 + nv), eng.fr_random(b, nm)) for a, b in seeds]
+    segs = lambda i: [(H, 0, 1, 9 + nv, vec[i][0], 0, 1), (G, 0, 1, nm, vec[i][1], 0, 1)]  # noqa: E731
+
+    def blocking():
+        return [eng.msm_fr_multi(segs(i)) for i in range(4)]
+
+    def on_lanes():
+        tk = [eng.msm_fr_multi_submit(segs(i)) for i in range(4)]
+        return [eng.msm_wait(x) for x in tk]
+
+    tb, rb = med_of(blocking)
+    tl, rl = med_of(on_lanes)
+    terms = 9 + nv + nm
+    entry = {"terms_per_commitment": terms, "setup_ms_both_tables": setup_ms,
+             "blocking": {"four_commitments_ms": tb * 1e3, "ms_per_commitment": tb / 4 * 1e3, "points_per_s": 4 * terms / tb},
+             "on_lanes": {"four_commitments_ms": tl * 1e3, "ms_per_commitment": tl / 4 * 1e3, "points_per_s": 4 * terms / tl},
+             "same_result": bool(rb == rl)}
+    if orc is not None:
+        want = [orc.g0_mul((orc.synth_dot(SEED_H, a, 9 + nv) + orc.synth_dot(SEED_G, b, nm)) % N_ORDER) for a, b in seeds]
+        entry["matches_oracle_closed_form"] = bool(rb == want)
+    for a, b in vec:
+        a.free()
+        b.free()
+    H.free()
+    G.free()
+    # the weighted-norm-linear argument over |l| = 2^20, |n| = 2^19 (go/bppp/docs_test.go:1269-1338): all rounds'
+    # X / R commitments and generator folds on the device, final check l, n opened against C
+    w = bpm.WNLA(eng)
+    w.synthetic(0xABCC, 1 << 20, 1 << 19)
+    runs = [w.synthetic(0xABCD + i, 1 << 20, 1 << 19) for i in range(5)]
+    entry["wnla_2p20"] = {"median_ms": statistics.median(r["ms_run"] for r in runs), "rounds": runs[0]["rounds"],
+                          "final_check_passes": all(r["ok"] for r in runs), "runs": 5,
+                          "setup_ms": statistics.median(r["ms_setup"] for r in runs)}
+    out["bppp_2p20"] = entry
     return out
 
 

@@ -82,3 +82,29 @@ def test_bench_bare_command_two_gpus(orc):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["points_per_gpu"] == 1 << 20
     assert bytes.fromhex(out["config"]["result_xy"]) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, 1 << 21)
+
+
+def test_bench_rank_path_with_a_one_rank_rccl_group(orc):
+    """bench.py's N > 1 code on one GPU: BENCH_FORCE_DIST=1 makes the single rank open an RCCL process group and
+    run every step's partial sum through sharding.AsyncExchange (side stream, batched all_gather, finish_batch)
+    and the barriers -- the code the driver's 2/4/8-GPU runs execute, which a one-GPU box otherwise never
+    touches.  The line must carry the exact sum (closed form), a non-zero exchange time and the `ranks` block
+    that an N > 1 line proves itself with (world size, devices seen by RCCL, per-rank kernel time)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    n = 1 << 20
+    assert out["n_gpus"] == 1 and out["config"]["points_total"] == n
+    assert bytes.fromhex(out["config"]["result_xy"]) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, n)
+    assert out["single_call"]["same_result"] is True
+    assert out["host_us_per_step"]["exchange"] > 0
+    rk = out["ranks"]
+    assert rk["world_size"] == 1 and rk["backend"] == "nccl" and rk["distinct_devices"] == 1 and rk["all_distinct"]
+    assert len(rk["per_rank"]) == 1 and rk["per_rank"][0]["points"] == n
+    assert 0 < rk["k_accumulate_ms_min"] <= rk["k_accumulate_ms_max"] < 5
+    assert rk["per_rank"][0]["pci_bus_id"] and rk["per_rank"][0]["device_name"]
