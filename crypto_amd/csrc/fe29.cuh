@@ -149,14 +149,18 @@ __device__ __forceinline__ fe fe_mul_portable(const fe& a, const fe& b) {
 }
 
 // (a*b + c*d) / R mod p with ONE Montgomery reduction (the reduction is 81 of a product's 162
-// multiply-adds).  Plain C++: four operands are 36 inputs, above the 30-operand limit of an
-// inline-asm statement, and the compiler's product-scanning code (v_mad_i64_i32 for the signed
-// terms, v_mad_u64_u32 for m*p) is within ~10 % of the generated asm.
+// multiply-adds).  fe_mul2add is the generated single-statement asm (fe_mul_gen.inc: 45 operands -- hipcc
+// takes them; the 30-operand limit is GCC's): 243 multiply-adds + 44 other instructions = 287, where the
+// compiler's code for the C++ below is ~320 (extra 64-bit moves and v_lshl_add_u64 around its
+// v_mad_u64_u32 quotient terms).  The C++ form stays as the portable restatement the self test compares with.
 // Bounds: every |a.v[i]*b.v[j]|, |c.v[i]*d.v[j]| < 2^58 (all four operands with limb magnitude
 // < 2^29: normalised values or differences of two normalised values), so a column holds at most
 // 27 terms < 2^58 plus a carry < 2^35: below 2^63.  Output: norm, value in
 // (-(|ab|+|cd|)/R, (|ab|+|cd|)/R + p).
 __device__ __forceinline__ fe fe_mul2add(const fe& a, const fe& b, const fe& c, const fe& d) {
+  return fe_mul2add_asm(a, b, c, d);
+}
+__device__ __forceinline__ fe fe_mul2add_portable(const fe& a, const fe& b, const fe& c, const fe& d) {
   i64 acc = 0;
   i32 m[9];
   fe r;

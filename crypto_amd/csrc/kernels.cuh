@@ -1838,6 +1838,8 @@ __global__ void __launch_bounds__(256) k_selftest(u32* __restrict__ errs, u32 n)
     fe d1 = fe_sub(b, c), d2 = fe_sub(c, a);
     fe f1 = fe_canon(fe_mul2add(d1, d2, fe_neg(a), b)), f2 = fe_canon(fe_sub(fe_mul(d1, d2), fe_mul(a, b)));
     for (int j = 0; j < 9; j++) bad |= (f1.v[j] != f2.v[j]) ? 128u : 0u;
+    fe g1 = fe_mul2add(d1, d2, fe_neg(a), b), g2 = fe_mul2add_portable(d1, d2, fe_neg(a), b);  // limb-identical
+    for (int j = 0; j < 9; j++) bad |= (g1.v[j] != g2.v[j]) ? 128u : 0u;
   }
   // device GLV split: |k1|, |k2| < 2^129 and k1 + k2 lambda == m (mod n), m the signed representative
   {

@@ -74,6 +74,58 @@ def emit(square):
     return L
 
 
+def emit2():
+    """(a*b + c*d) / R: both products' terms in every column, ONE Montgomery reduction.  Operands:
+    r0..r8 = %0..%8 (early clobber), a = %9.., b = %18.., c = %27.., d = %36..  Column bound: 18 products and 9
+    quotient terms below 2^58 each plus a carry below 2^35: under 2^63 (fe_mul2add's contract in fe29.cuh)."""
+    L = []
+    for j in range(9):
+        L.append(f"s_mov_b32 s{SP + j}, {P[j]:#x}")
+    L.append(f"s_mov_b32 s{SP + 9}, {NP:#x}")
+    r = [f"%{j}" for j in range(9)]
+    a = [f"%{9 + j}" for j in range(9)]
+    b = [f"%{18 + j}" for j in range(9)]
+    c = [f"%{27 + j}" for j in range(9)]
+    d = [f"%{36 + j}" for j in range(9)]
+    first = True
+
+    def mad(x, y):
+        nonlocal first
+        src2 = "0" if first else ACC
+        first = False
+        L.append(f"v_mad_i64_i32 {ACC}, vcc, {x}, {y}, {src2}")
+
+    for k in range(17):
+        lo, hi = max(0, k - 8), min(k, 8)
+        for i in range(lo, hi + 1):
+            mad(a[i], b[k - i])
+            mad(c[i], d[k - i])
+        if k <= 8:
+            for i in range(0, k):
+                mad(r[i], f"s{SP + k - i}")
+            L.append(f"v_mul_lo_u32 {r[k]}, v0, s{SP + 9}")
+            L.append(f"v_and_b32 {r[k]}, 0x1fffffff, {r[k]}")
+            mad(r[k], f"s{SP}")
+            L.append(f"v_ashrrev_i64 {ACC}, 29, {ACC}")
+        else:
+            for i in range(lo, hi + 1):
+                mad(r[i], f"s{SP + k - i}")
+            L.append(f"v_and_b32 {r[k - 9]}, 0x1fffffff, v0")
+            L.append(f"v_ashrrev_i64 {ACC}, 29, {ACC}")
+    L.append(f"v_mov_b32 {r[8]}, v0")
+    return L
+
+
+def function2(name):
+    lines = emit2()
+    body = "\n".join(f'      "{l}\\n\\t"' for l in lines)
+    outs = ", ".join(f'"=&v"(r.v[{j}])' for j in range(9))
+    ins = ", ".join(", ".join(f'"v"({x}.v[{j}])' for j in range(9)) for x in "abcd")
+    clob = '"vcc", "v0", "v1", ' + ", ".join(f'"s{SP + j}"' for j in range(10))
+    sig = f"__device__ __forceinline__ fe {name}(const fe& a, const fe& b, const fe& c, const fe& d) {{\n  fe r;\n"
+    return f"{sig}  asm(\n{body}\n      : {outs}\n      : {ins}\n      : {clob});\n  return r;\n}}\n"
+
+
 def function(name, square):
     lines = emit(square)
     body = "\n".join(f'      "{l}\\n\\t"' for l in lines)
@@ -98,4 +150,6 @@ if __name__ == "__main__":
         f.write(function("fe_mul", False))
         f.write("\n")
         f.write(function("fe_sqr", True))
+        f.write("\n")
+        f.write(function2("fe_mul2add_asm"))
     print("wrote", dst)
