@@ -169,7 +169,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_PEER_A, WS_PEER_B, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_PEER_A, WS_PEER_B, WS_SMTABLE, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -497,6 +497,40 @@ static void normalize_into(bn256_ctx* ctx, const xyzz_mem* in, aff_mem* out, siz
                      (i32*)ctx->ws[WS_PARTIALS], (u32)n, B);
 }
 
+// xs[i] = s_(i mod bs or i) * in[i or 0] for i < n, per-point scalars already on the device: one quad per point and
+// GLV half up to SCALAR_MUL_QUAD_MAX points (xs then needs 2n entries; k_glv_combine joins the halves), above it
+// one lane per point with a per-lane window table in HBM (k_scalar_mul_win), SMW_MAX_POINTS points per launch.
+// BN256_SCALAR_MUL_V1=1 (environment): round 2's joint binary chain instead (A/B runs).
+#define SCALAR_MUL_QUAD_MAX ((size_t)1 << 14)
+static int launch_scalar_mul(bn256_ctx* ctx, const aff_mem* in, const uint8_t* d_scalars, xyzz_mem* xs, size_t n,
+                             u32 broadcast_scalar, u32 broadcast_point) {
+  static const bool v1 = getenv("BN256_SCALAR_MUL_V1") && atoi(getenv("BN256_SCALAR_MUL_V1")) != 0;
+  hipStream_t s = ctx->stream;
+  if (n <= SCALAR_MUL_QUAD_MAX && (broadcast_scalar == 0 || broadcast_scalar == 1)) {
+    hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, s, in, d_scalars, xs, (u32)n,
+                       broadcast_scalar, broadcast_point);
+    hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, s, xs, (u32)n);
+    return BN256_OK;
+  }
+  if (v1) {
+    hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, s, in, d_scalars, xs, (u32)n, broadcast_scalar,
+                       broadcast_point);
+    return BN256_OK;
+  }
+  const size_t per = std::min(n, SMW_MAX_POINTS);
+  int rc = ws_reserve(ctx, WS_SMTABLE, per * SMW_ENTRIES * SMW_ENTRY_WORDS * sizeof(i32));
+  if (rc) return rc;
+  for (size_t at = 0; at < n; at += per) {
+    const size_t m = std::min(per, n - at);
+    // scalar index of point at + j: (at + j) mod broadcast_scalar -- `at` is a multiple of 2^20, hence of any
+    // small power-of-two period; other periods only ever come with n <= 2^20 (one launch)
+    hipLaunchKernelGGL(k_scalar_mul_win, dim3(nblocks(m, 256)), dim3(256), 0, s, broadcast_point ? in : in + at,
+                       broadcast_scalar ? d_scalars : d_scalars + at * 32, xs + at, (u32)m, broadcast_scalar, broadcast_point,
+                       (i32*)ctx->ws[WS_SMTABLE]);
+  }
+  return BN256_OK;
+}
+
 // With wide windows the top window is much narrower than the others (c = 20: 13 windows, the top one
 // holds bits 240..254 of a scalar below n/2, values <= 18395 of 2^19): its 2^20 digits per 2^20 points
 // would all land in the first 3.5 % of the buckets and make the sort's first groups three times as
@@ -565,8 +599,8 @@ static int bases_precompute(bn256_ctx* ctx, bn256_bases* b) {
     if ((rc = ws_reserve(ctx, WS_SCALARS, sizeof(inv_be)))) return rc;
     HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], inv_be, sizeof(inv_be), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // inv_be is on this stack
-    hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(b->n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)top,
-                       (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)b->n, TOP_SCALES, 0u);
+    if ((rc = launch_scalar_mul(ctx, (const aff_mem*)top, (const uint8_t*)ctx->ws[WS_SCALARS], xs, b->n, TOP_SCALES, 0u)))
+      return rc;
     normalize_into(ctx, xs, top, b->n);
   }
   HIPCHK(hipGetLastError());
@@ -1548,9 +1582,8 @@ extern "C" int bn256_msm_multi_submit(bn256_ctx* ctx, int k, const bn256_bases* 
 }
 
 // ---------------------------------------------------------------------------- element-wise
-// up to this many points a per-point scalar multiplication runs one quad per point (latency), above
-// it one lane per point (throughput): 2^14 quads are one wave per SIMD
-#define SCALAR_MUL_QUAD_MAX ((size_t)1 << 14)
+// (SCALAR_MUL_QUAD_MAX, above: up to that many points a per-point scalar multiplication runs one quad per point
+// (latency), above it one lane per point (throughput): 2^14 quads are one wave per SIMD)
 // generator folds: one quad per output up to here (a single latency chain), one lane per output above
 static size_t fold_quad_max() {
   static const size_t v = [] {
@@ -1744,10 +1777,15 @@ static int fold_points(bn256_ctx* ctx, const aff_mem* lo, const aff_mem* hi, u32
     hipLaunchKernelGGL(k_fold_points_quad, dim3(nblocks(n * 4, 256), 1), dim3(256), 0, ctx->stream, lo, hi, stride, jsf,
                        jsf, xs, n_lo, n_hi);
   } else {  // both GLV halves on one doubling chain
+    static const bool v1 = getenv("BN256_FOLD_XYZZ") && atoi(getenv("BN256_FOLD_XYZZ")) != 0;  // round 2's kernel (A/B runs)
     jsf_arg jsf[2];
     jsf_build_glv(s_lo_be, s_hi_be, jsf);
-    hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf[0], jsf[1], xs,
-                       n_lo, n_hi);
+    if (v1)
+      hipLaunchKernelGGL(k_fold_points_xyzz, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf[0], jsf[1],
+                         xs, n_lo, n_hi);
+    else
+      hipLaunchKernelGGL(k_fold_points, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, lo, hi, stride, jsf[0], jsf[1], xs,
+                         n_lo, n_hi);
   }
   *xs_out = xs;
   return BN256_OK;
@@ -1769,13 +1807,7 @@ static int scalar_mul_into(bn256_ctx* ctx, const aff_mem* in, size_t n, const ui
     size_t sb = n * 32;
     if ((rc = ws_reserve(ctx, WS_SCALARS, sb))) return rc;
     HIPCHK(hipMemcpyAsync(ctx->ws[WS_SCALARS], scalars_be, sb, hipMemcpyHostToDevice, ctx->stream));
-    if (n <= SCALAR_MUL_QUAD_MAX) {  // two GLV half-chains per point, then out[i] + phi(out[n + i])
-      hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, in,
-                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
-      hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
-    } else
-      hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, in,
-                         (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 0u);
+    if ((rc = launch_scalar_mul(ctx, in, (const uint8_t*)ctx->ws[WS_SCALARS], xs, n, 0u, 0u))) return rc;
   }
   normalize_into(ctx, xs, r->d, n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2055,13 +2087,8 @@ extern "C" int bn256_random_bases(bn256_ctx* ctx, uint64_t seed, size_t first, s
       hipLaunchKernelGGL(k_points_from_be, dim3(1), dim3(256), 0, ctx->stream, (const uint8_t*)tmp, d_g0, 1u, ctx->d_err);
       hipLaunchKernelGGL(k_synth_scalars, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
                          (uint8_t*)ctx->ws[WS_SCALARS], (u64)seed, (u64)first, (u32)n, 1u);
-      if (n <= SCALAR_MUL_QUAD_MAX) {
-        hipLaunchKernelGGL(k_scalar_mul_quad, dim3(nblocks(n * 4, 256), 2), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
-                           (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
-        hipLaunchKernelGGL(k_glv_combine, dim3(nblocks(n * 4, 256)), dim3(256), 0, ctx->stream, xs, (u32)n);
-      } else
-        hipLaunchKernelGGL(k_scalar_mul, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, (const aff_mem*)d_g0,
-                           (const uint8_t*)ctx->ws[WS_SCALARS], xs, (u32)n, 0u, 1u);
+      rc = launch_scalar_mul(ctx, (const aff_mem*)d_g0, (const uint8_t*)ctx->ws[WS_SCALARS], xs, n, 0u, 1u);
+      if (rc) { bn256_bases_free(ctx, b); return rc; }
       normalize_into(ctx, xs, b->d, n);
       e = hipStreamSynchronize(ctx->stream);
     }

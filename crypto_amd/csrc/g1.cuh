@@ -272,6 +272,96 @@ __device__ __forceinline__ void xyzz_add(xyzz& r, const xyzz& a, const xyzz& b) 
   r.zzz = zzz3;
 }
 
+// ------------------------------------------------------------------ Jacobian accumulators
+// The element-wise chains (generator folds, the h1 loop: go/bp/main.go:156-159,355-356) are doublings with
+// an addition of an AFFINE table entry now and then.  There Jacobian coordinates (x = X/Z^2, y = Y/Z^3) are
+// cheaper than XYZZ: the doubling is 3 squarings + 3 products with 5 reductions (XYZZ: 3 + 6 with 8), the
+// mixed addition one squaring more (Z^2 is not carried along).  Bucket accumulation (additions only) stays
+// XYZZ.  Infinity: Z has all limbs zero (only ever written explicitly, as for XYZZ).
+struct jac {
+  fe x, y, z;
+};
+__device__ __forceinline__ bool jac_is_inf(const jac& a) { return fe_limbs_all_zero(a.z); }
+__device__ __forceinline__ void jac_set_inf(jac& a) {
+  a.x = fe_zero();
+  a.y = fe_zero();
+  a.z = fe_zero();
+}
+// r = 2a (dbl-2009-l with S = 4 X YY as a product): XX, YY, MM squarings; S, Z3 products; Y3 = M (S - T) - 8 YYYY
+// as M (S - T) - (4 YY)(2 YY) under one reduction.  Inputs normalised with |X|, |Y|, |Z| < 6p; outputs
+// normalised, |X3| < 4p, |Y3|, |Z3| < 2p.
+__device__ __forceinline__ void jac_dbl(jac& r, const jac& a) {
+  if (jac_is_inf(a)) {
+    jac_set_inf(r);
+    return;
+  }
+  fe xx = fe_sqr(a.x);
+  fe yy = fe_sqr(a.y);
+  fe w = fe_norm(fe_add(yy, yy));                    // 2 YY
+  fe w2 = fe_norm(fe_small_mul(yy, 4));              // 4 YY (normalised: every term of the double product < 2^58)
+  fe s = fe_mul(a.x, w2);                            // 4 X YY
+  fe m = fe_norm(fe_small_mul(xx, 3));               // 3 XX
+  fe t = fe_norm(fe_sub(fe_sub(fe_sqr(m), s), s));   // X3 = M^2 - 2S
+  fe y3 = fe_mul2add(m, fe_sub(s, t), fe_neg(w2), w);  // M (S - X3) - 8 YYYY
+  fe z3 = fe_mul(fe_add(a.y, a.y), a.z);             // 2 Y Z   (2Y: limbs < 2^30, times normalised: < 2 * 2^58)
+  r.x = t;
+  r.y = y3;
+  r.z = z3;
+}
+// Rare paths of the mixed addition, out of line and by value (see xyzz_madd_special)
+__device__ __noinline__ jac jac_madd_special(fe x2, fe y2, fe rr) {
+  jac r;
+  if (fe_is_zero_mod_p(rr)) {  // P == Q: 2 (x2, y2, 1)
+    jac a;
+    a.x = x2;
+    a.y = fe_norm(y2);
+    a.z = fe_one();
+    jac_dbl(r, a);
+  } else {
+    jac_set_inf(r);  // P == -Q
+  }
+  return r;
+}
+// acc += (x2, y2), affine operand not at infinity (the madd-2007-bl flow without its factors of two):
+// 3 squarings + 6 products + one double product, 10 reductions.  x2, y2: limb magnitudes < 2^29.
+__device__ __forceinline__ void jac_madd(jac& acc, const fe& x2, const fe& y2) {
+  if (jac_is_inf(acc)) {
+    acc.x = x2;
+    acc.y = fe_norm(y2);
+    acc.z = fe_one();
+    return;
+  }
+  fe z1z1 = fe_sqr(acc.z);
+  fe u2 = fe_mul(x2, z1z1);
+  fe s2 = fe_mul(y2, fe_mul(acc.z, z1z1));
+  fe h = fe_sub(u2, acc.x);
+  fe rr = fe_sub(s2, acc.y);
+  fe hh = fe_sqr(h);
+  if (__builtin_expect(fe_maybe_zero_sq(hh), 0)) {
+    if (fe_is_zero_mod_p(h)) {
+      acc = jac_madd_special(x2, y2, rr);
+      return;
+    }
+  }
+  fe hhh = fe_mul(h, hh);
+  fe v = fe_mul(acc.x, hh);
+  fe x3 = fe_norm(fe_sub(fe_sub(fe_sub(fe_sqr(rr), hhh), v), v));
+  fe y3 = fe_mul2add(rr, fe_sub(v, x3), fe_neg(acc.y), hhh);
+  acc.z = fe_mul(acc.z, h);
+  acc.x = x3;
+  acc.y = y3;
+}
+__device__ __forceinline__ void jac_to_xyzz(xyzz& r, const jac& a) {
+  if (jac_is_inf(a)) {
+    xyzz_set_inf(r);
+    return;
+  }
+  r.x = a.x;
+  r.y = a.y;
+  r.zz = fe_sqr(a.z);
+  r.zzz = fe_mul(a.z, r.zz);
+}
+
 // ------------------------------------------------------------------ quad-cooperative addition
 // The bucket-reduction tail is a chain of dependent XYZZ additions executed by very few
 // waves, and one wave alone issues a VALU instruction only every ~9.5 clk, so an addition is

@@ -1498,6 +1498,189 @@ __global__ void __launch_bounds__(256) k_scalar_mul(const aff_mem* __restrict__ 
   xyzz_store(&out[i], acc);
 }
 
+// ---- the same for MANY points (h1[i] = yinvn[i] * H[i] over a whole generator vector, go/bp/main.go:156-159;
+// the synthetic generators): one lane per point, throughput work.  The joint binary chain above makes a wave
+// run an addition at EVERY bit (three of four lanes need one), 130 general additions of 14 products.  Here:
+// signed fixed 4-bit windows over both GLV halves -- every lane adds at the same steps, 33 windows x 2
+// additions -- with a per-lane table T[m] = m P, m = 1..8, normalised to AFFINE with one inversion (Montgomery's
+// trick over the seven Z), so that every addition is a mixed one, and a Jacobian accumulator (g1.cuh: cheaper
+// doublings): 130 doublings + 66 mixed additions + the table (7 additions, one inversion) instead of
+// 130 x (doubling + general addition) -- 2^20 points 17.5 -> see DESIGN.md 6.
+// Table memory: SMW_ENTRY_WORDS 32-bit words per entry, 8 entries per lane, in HBM (`table`; the caller
+// launches at most SMW_MAX_POINTS points at a time): while it is being built an entry holds the Jacobian
+// (X, Y, Z), afterwards the affine (x, y) in its first 18 words; a lane reads its entries as whole 128-byte
+// lines.  The prefix products of the seven Z live in LDS (63 KiB per workgroup of 256).
+#define SMW_ENTRY_WORDS 32u
+#define SMW_ENTRIES 8u
+#define SMW_MAX_POINTS ((size_t)1 << 20)
+__device__ __forceinline__ void smw_store3(i32* e, const fe& a, const fe& b, const fe& c) {
+  int4* q = reinterpret_cast<int4*>(e);
+  i32 t[28];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    t[k] = a.v[k];
+    t[9 + k] = b.v[k];
+    t[18 + k] = c.v[k];
+  }
+  t[27] = 0;
+#pragma unroll
+  for (int k = 0; k < 7; k++) q[k] = make_int4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
+}
+__device__ __forceinline__ void smw_load2(fe& a, fe& b, const i32* e) {
+  const int4* q = reinterpret_cast<const int4*>(e);
+  i32 t[20];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    int4 v = q[k];
+    t[4 * k] = v.x;
+    t[4 * k + 1] = v.y;
+    t[4 * k + 2] = v.z;
+    t[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    a.v[k] = t[k];
+    b.v[k] = t[9 + k];
+  }
+}
+__device__ __forceinline__ void smw_load3(fe& a, fe& b, fe& c, const i32* e) {
+  const int4* q = reinterpret_cast<const int4*>(e);
+  i32 t[28];
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    int4 v = q[k];
+    t[4 * k] = v.x;
+    t[4 * k + 1] = v.y;
+    t[4 * k + 2] = v.z;
+    t[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    a.v[k] = t[k];
+    b.v[k] = t[9 + k];
+    c.v[k] = t[18 + k];
+  }
+}
+// signed 4-bit windows of a 130-bit magnitude, LSB first: digit j in [-8, 8] as (|d| | sign << 4), six digits
+// of five bits per word
+__device__ __forceinline__ void smw_recode(u32 (&pack)[6], const u32 (&k)[5]) {
+#pragma unroll
+  for (int w = 0; w < 6; w++) pack[w] = 0;
+  u32 carry = 0;
+#pragma unroll
+  for (int j = 0; j < 33; j++) {
+    const int bit = 4 * j;
+    u32 raw = ((k[bit >> 5] >> (bit & 31)) & 15u) + carry;  // 4 j never straddles a word
+    const bool big = raw > 8u;
+    const u32 dig = big ? 16u - raw : raw;
+    carry = big ? 1u : 0u;
+    pack[j / 6] |= (dig | (big ? 16u : 0u)) << (5 * (j % 6));
+  }
+}
+__device__ __forceinline__ u32 smw_digit(const u32 (&pack)[6], u32 j) {
+  const u32 w = j / 6u;
+  u32 r = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) r = (w == (u32)i) ? pack[i] : r;
+  return (r >> (5u * (j - 6u * w))) & 31u;
+}
+__global__ void __launch_bounds__(256, 2) k_scalar_mul_win(const aff_mem* __restrict__ in,
+                                                           const uint8_t* __restrict__ scalars_be,
+                                                           xyzz_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
+                                                           u32 broadcast_point, i32* __restrict__ table) {
+  __shared__ i32 pre[7][9][256];  // prefix products Z_2 ... Z_m, m = 2..8: [m - 2][limb][thread]
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
+  if (i >= n) return;  // no barrier below: every lane works on its own LDS column and table lines
+  fe px, py;
+  xyzz res;
+  xyzz_set_inf(res);
+  if (!aff_load(px, py, &in[broadcast_point ? 0 : i], false)) {
+    xyzz_store(&out[i], res);
+    return;
+  }
+  u32 pk1[6], pk2[6];
+  bool s1, s2;  // signs of the two halves' base points: +-P, +-phi(P)
+  {
+    u32 k[8], k1[5], k2[5];
+    scalar_load_be(k, scalars_be + (size_t)(broadcast_scalar ? i % broadcast_scalar : i) * 32);
+    const bool neg = scalar_reduce_signed(k);
+    bool n1, n2;
+    glv_split_dev(k, k1, n1, k2, n2);
+    s1 = neg != n1;
+    s2 = neg != n2;
+    smw_recode(pk1, k1);
+    smw_recode(pk2, k2);
+  }
+  i32* const tab = table + (size_t)i * (SMW_ENTRIES * SMW_ENTRY_WORDS);
+  // ---- table: m P for m = 1..8, Jacobian first
+  {
+    jac t;
+    t.x = px;
+    t.y = py;
+    t.z = fe_one();
+    smw_store3(tab, t.x, t.y, t.z);
+    jac d;
+    jac_dbl(d, t);  // 2P; P has prime order: no m P, m <= 8, is infinity and (m - 1) P != +-P
+    t = d;
+    fe run = t.z;
+#pragma unroll 1
+    for (u32 m = 2; m <= SMW_ENTRIES; m++) {
+      if (m > 2) {
+        jac_madd(t, px, py);
+        run = fe_mul(run, t.z);
+      }
+      smw_store3(tab + (m - 1) * SMW_ENTRY_WORDS, t.x, t.y, t.z);
+#pragma unroll
+      for (int k = 0; k < 9; k++) pre[m - 2][k][tid] = run.v[k];
+    }
+    fe inv = fe_inv(run);  // 1 / (Z_2 ... Z_8)
+#pragma unroll 1
+    for (u32 m = SMW_ENTRIES; m >= 2; m--) {
+      fe X, Y, Z;
+      smw_load3(X, Y, Z, tab + (m - 1) * SMW_ENTRY_WORDS);
+      fe zi = inv;
+      if (m > 2) {
+        fe prev;
+#pragma unroll
+        for (int k = 0; k < 9; k++) prev.v[k] = pre[m - 3][k][tid];
+        zi = fe_mul(inv, prev);  // 1 / Z_m
+        inv = fe_mul(inv, Z);
+      }
+      const fe zi2 = fe_sqr(zi);
+      const fe ax = fe_mul(X, zi2), ay = fe_mul(Y, fe_mul(zi2, zi));
+      smw_store3(tab + (m - 1) * SMW_ENTRY_WORDS, ax, ay, Z);
+    }
+  }
+  // ---- 33 windows, most significant first: 4 doublings, then +-T[|d1|] and +-phi(T[|d2|])
+  const fe beta = {FE_BETA_LIMBS};
+  jac acc;
+  jac_set_inf(acc);
+#pragma unroll 1
+  for (int j = 32; j >= 0; j--) {
+    if (!jac_is_inf(acc)) {
+#pragma unroll 1
+      for (int r = 0; r < 4; r++) {
+        jac t;
+        jac_dbl(t, acc);
+        acc = t;
+      }
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const u32 f = h ? smw_digit(pk2, (u32)j) : smw_digit(pk1, (u32)j);
+      const u32 dig = f & 15u;
+      if (dig == 0) continue;
+      fe tx, ty;
+      smw_load2(tx, ty, tab + (dig - 1u) * SMW_ENTRY_WORDS);
+      if (h) tx = fe_mul(tx, beta);
+      const bool neg = ((f >> 4) != 0) != (h ? s2 : s1);
+      jac_madd(acc, tx, neg ? fe_neg(ty) : ty);
+    }
+  }
+  jac_to_xyzz(res, acc);
+  xyzz_store(&out[i], res);
+}
+
 // The same for few points (the provers' small vectors: a call is one latency chain, not throughput
 // work): one quad per point and GLV half, quad-cooperative doubling / addition, 2-bit windows over
 // {P, 2P, 3P} -- 130 doublings + <= 65 additions in 3 + 4 multiplication stages each instead of
@@ -1652,9 +1835,10 @@ __global__ void __launch_bounds__(256) k_glv_combine(xyzz_mem* __restrict__ out,
 // same joint sparse form, still without divergence (the digits are the grid's), at ~12
 // multiplications per digit and enough waves per SIMD to issue back to back.  P, Q stay affine
 // (mixed additions), P+Q and P-Q stay XYZZ (general additions).
-__global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
-                                                        u32 stride, jsf_arg jsf0, jsf_arg jsf1,
-                                                        xyzz_mem* __restrict__ out, u32 n_lo, u32 n_hi) {
+__global__ void __launch_bounds__(256, 2) k_fold_points_xyzz(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
+                                                             u32 stride, jsf_arg jsf0, jsf_arg jsf1,
+                                                             xyzz_mem* __restrict__ out, u32 n_lo, u32 n_hi) {
+  // (round 2's form, kept for A/B runs: BN256_FOLD_XYZZ=1)
   // GLV with ONE shared doubling chain (throughput, not latency, is what counts here): jsf0 holds
   // the digits of (s_lo', s_hi'), jsf1 those of (s_lo'', s_hi''), s = s' + s'' lambda; a digit of
   // jsf1 adds phi(T) = (beta X, Y, ZZ, ZZZ) of the same table entry T.  130 doublings instead of 257.
@@ -1720,6 +1904,118 @@ __global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restric
     }
   }
   xyzz_store(&out[i], acc);
+}
+
+// Round 3's form of the same fold: P + Q and P - Q are made AFFINE -- lambda = (yQ -+ yP) / (xQ - xP), both from
+// ONE inversion per output (~20 k instructions against ~550 k for the chain) -- so that all ~130 additions of
+// the chain are mixed ones (10 products; the XYZZ table entries cost a general addition of 14 for half of
+// them), and the accumulator is Jacobian (g1.cuh: the doubling is 5 reductions instead of 8).  LDS holds
+// (x, y) of P + Q and P - Q and beta x of all four table points: [entry][limb][thread], 72 KiB as before.
+enum { FT_XS, FT_YS, FT_XD, FT_YD, FT_BPX, FT_BQX, FT_BXS, FT_BXD, FT_ENTRIES };
+__global__ void __launch_bounds__(256, 2) k_fold_points(const aff_mem* __restrict__ lo, const aff_mem* __restrict__ hi,
+                                                        u32 stride, jsf_arg jsf0, jsf_arg jsf1,
+                                                        xyzz_mem* __restrict__ out, u32 n_lo, u32 n_hi) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 tid = threadIdx.x;
+  u32 n = n_lo > n_hi ? n_lo : n_hi;
+  if (i >= n) return;
+  __shared__ i32 sd[FT_ENTRIES][9][256];
+  auto put = [&](int e, const fe& v) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) sd[e][k][tid] = v.v[k];
+  };
+  auto get = [&](int e) {
+    fe v;
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.v[k] = sd[e][k][tid];
+    return v;
+  };
+  fe px, py, qx, qy;
+  const bool hp = i < n_lo && aff_load(px, py, &lo[(size_t)i * stride], false);
+  const bool hq = i < n_hi && aff_load(qx, qy, &hi[(size_t)i * stride], false);
+  bool hs = false, hd = false;  // P + Q, P - Q are not infinity
+  {
+    fe xs = fe_zero(), ys = fe_zero(), xd = fe_zero(), yd = fe_zero();
+    if (hp && hq) {
+      const fe dx = fe_sub(qx, px);
+      if (!fe_is_zero_mod_p(dx)) {
+        const fe inv = fe_inv(dx);
+        const fe ls = fe_mul(fe_sub(qy, py), inv), ld = fe_mul(fe_neg(fe_add(qy, py)), inv);
+        const fe sx = fe_add(px, qx);
+        xs = fe_norm(fe_sub(fe_sqr(ls), sx));
+        ys = fe_norm(fe_sub(fe_mul(ls, fe_sub(px, xs)), py));
+        xd = fe_norm(fe_sub(fe_sqr(ld), sx));
+        yd = fe_norm(fe_sub(fe_mul(ld, fe_sub(px, xd)), py));
+        hs = hd = true;
+      } else {  // P == +-Q: one of the two is 2P, the other infinity
+        xyzz t;
+        xyzz_dbl_affine(t, px, py);
+        if (fe_is_zero_mod_p(fe_sub(qy, py)))
+          hs = xyzz_to_affine(xs, ys, t);
+        else
+          hd = xyzz_to_affine(xd, yd, t);
+      }
+    } else if (hp) {  // Q is infinity: P + Q = P - Q = P
+      xs = xd = px;
+      ys = yd = py;
+      hs = hd = true;
+    } else if (hq) {  // P is infinity: P + Q = Q, P - Q = -Q
+      xs = xd = qx;
+      ys = qy;
+      yd = fe_neg(qy);
+      hs = hd = true;
+    }
+    const fe beta = {FE_BETA_LIMBS};
+    put(FT_XS, xs);
+    put(FT_YS, ys);
+    put(FT_XD, xd);
+    put(FT_YD, yd);
+    put(FT_BPX, hp ? fe_mul(px, beta) : fe_zero());
+    put(FT_BQX, hq ? fe_mul(qx, beta) : fe_zero());
+    put(FT_BXS, fe_mul(xs, beta));
+    put(FT_BXD, fe_mul(xd, beta));
+  }
+  jac acc;
+  jac_set_inf(acc);
+  const int len = (int)(jsf0.len > jsf1.len ? jsf0.len : jsf1.len);
+#pragma unroll 1
+  for (int j = len - 1; j >= 0; j--) {
+    {
+      jac t;
+      jac_dbl(t, acc);
+      acc = t;
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {  // h = 1: the phi half, (beta x, y) of the same table entry
+      const u32 d = ((h ? jsf1.w[j >> 3] : jsf0.w[j >> 3]) >> ((j & 7) * 4)) & 15u;  // words beyond len are zero
+      if (d == 0) continue;  // uniform over the grid, as every branch on d below
+      const u32 d0 = d & 3u, d1 = d >> 2;
+      const bool neg = (d0 ? d0 : d1) == 3u;
+      fe tx, ty;
+      bool ok;
+      if (d1 == 0) {
+        ok = hp;
+        ty = py;
+        tx = h ? get(FT_BPX) : px;
+      } else if (d0 == 0) {
+        ok = hq;
+        ty = qy;
+        tx = h ? get(FT_BQX) : qx;
+      } else if (d0 == d1) {
+        ok = hs;
+        ty = get(FT_YS);
+        tx = get(h ? FT_BXS : FT_XS);
+      } else {
+        ok = hd;
+        ty = get(FT_YD);
+        tx = get(h ? FT_BXD : FT_XD);
+      }
+      if (ok) jac_madd(acc, tx, neg ? fe_neg(ty) : ty);
+    }
+  }
+  xyzz res;
+  jac_to_xyzz(res, acc);
+  xyzz_store(&out[i], res);
 }
 
 // out[i] = a_i * g + b_i * h: n independent 2-term Pedersen commitments with per-output scalars --
