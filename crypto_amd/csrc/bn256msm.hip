@@ -517,14 +517,17 @@ static int launch_scalar_mul(bn256_ctx* ctx, const aff_mem* in, const uint8_t* d
                        broadcast_point);
     return BN256_OK;
   }
-  const size_t per = std::min(n, SMW_MAX_POINTS);
-  int rc = ws_reserve(ctx, WS_SMTABLE, per * SMW_ENTRIES * SMW_ENTRY_WORDS * sizeof(i32));
+  // 1 KiB of table per point of a launch; when memory is short the launches shrink (multiples of 256 points)
+  size_t per = std::min(n, SMW_MAX_POINTS);
+  int rc;
+  while ((rc = ws_reserve(ctx, WS_SMTABLE, per * SMW_ENTRIES * SMW_ENTRY_WORDS * sizeof(i32))) == BN256_ENOMEM && per > 4096)
+    per = std::max<size_t>(4096, (per / 2) & ~(size_t)255);
   if (rc) return rc;
   for (size_t at = 0; at < n; at += per) {
     const size_t m = std::min(per, n - at);
-    // scalar index of point at + j: (at + j) mod broadcast_scalar -- `at` is a multiple of 2^20, hence of any
-    // small power-of-two period; other periods only ever come with n <= 2^20 (one launch)
-    hipLaunchKernelGGL(k_scalar_mul_win, dim3(nblocks(m, 256)), dim3(256), 0, s, broadcast_point ? in : in + at,
+    // scalar index of point at + j: (at + j) mod broadcast_scalar -- `at` is a multiple of 256, hence of any
+    // small power-of-two period (TOP_SCALES); other periods only ever come with one launch
+    hipLaunchKernelGGL(k_scalar_mul_win, dim3(nblocks(m, SMW_BLOCK)), dim3(SMW_BLOCK), 0, s, broadcast_point ? in : in + at,
                        broadcast_scalar ? d_scalars : d_scalars + at * 32, xs + at, (u32)m, broadcast_scalar, broadcast_point,
                        (i32*)ctx->ws[WS_SMTABLE]);
   }

@@ -1584,11 +1584,12 @@ __device__ __forceinline__ u32 smw_digit(const u32 (&pack)[6], u32 j) {
   for (int i = 0; i < 6; i++) r = (w == (u32)i) ? pack[i] : r;
   return (r >> (5u * (j - 6u * w))) & 31u;
 }
-__global__ void __launch_bounds__(256, 2) k_scalar_mul_win(const aff_mem* __restrict__ in,
+#define SMW_BLOCK 128
+__global__ void __launch_bounds__(SMW_BLOCK, 3) k_scalar_mul_win(const aff_mem* __restrict__ in,
                                                            const uint8_t* __restrict__ scalars_be,
                                                            xyzz_mem* __restrict__ out, u32 n, u32 broadcast_scalar,
                                                            u32 broadcast_point, i32* __restrict__ table) {
-  __shared__ i32 pre[7][9][256];  // prefix products Z_2 ... Z_m, m = 2..8: [m - 2][limb][thread]
+  __shared__ i32 pre[5][9][SMW_BLOCK];  // prefix products Z_2 ... Z_m for m = 3..7: [m - 3][limb][thread] (Z_2 itself is in the table)
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
   if (i >= n) return;  // no barrier below: every lane works on its own LDS column and table lines
   fe px, py;
@@ -1630,8 +1631,10 @@ __global__ void __launch_bounds__(256, 2) k_scalar_mul_win(const aff_mem* __rest
         run = fe_mul(run, t.z);
       }
       smw_store3(tab + (m - 1) * SMW_ENTRY_WORDS, t.x, t.y, t.z);
+      if (m >= 3 && m < SMW_ENTRIES) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) pre[m - 2][k][tid] = run.v[k];
+        for (int k = 0; k < 9; k++) pre[m - 3][k][tid] = run.v[k];
+      }
     }
     fe inv = fe_inv(run);  // 1 / (Z_2 ... Z_8)
 #pragma unroll 1
@@ -1641,8 +1644,13 @@ __global__ void __launch_bounds__(256, 2) k_scalar_mul_win(const aff_mem* __rest
       fe zi = inv;
       if (m > 2) {
         fe prev;
+        if (m == 3) {
+          fe x2, y2;
+          smw_load3(x2, y2, prev, tab + SMW_ENTRY_WORDS);  // Z_2
+        } else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) prev.v[k] = pre[m - 3][k][tid];
+          for (int k = 0; k < 9; k++) prev.v[k] = pre[m - 4][k][tid];
+        }
         zi = fe_mul(inv, prev);  // 1 / Z_m
         inv = fe_mul(inv, Z);
       }
