@@ -41,7 +41,8 @@ def load() -> C.CDLL:
     lib.bp_wnla_synthetic.argtypes = [vp, C.c_uint64, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_int)]
     lib.bp_ac_det.argtypes = [vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(AcCircuit), C.c_char_p, sz, C.POINTER(sz)]
-    lib.bp_ac_wlw.argtypes = [C.POINTER(AcCircuit), C.c_char_p]
+    if hasattr(lib, "bp_ac_wlw"):  # absent from an older build loaded through BPAMD_LIB (A/B runs)
+        lib.bp_ac_wlw.argtypes = [C.POINTER(AcCircuit), C.c_char_p]
     cp = C.c_char_p
     lib.bp_schnorr_msg.argtypes = [cp, sz, cp]
     lib.bp_schnorr_multisig.argtypes = [cp, cp, cp, cp, cp, cp]

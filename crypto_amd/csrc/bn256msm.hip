@@ -197,6 +197,7 @@ struct bn256_ctx {
   u32* h_err;       // pinned
   u32* d_flags;     // MSM_FLAG_* of the call in flight (kernels.cuh): the last two words of d_heavy's block; the
                     // packing kernel appends them to the packed results, so they reach the host with h_pack
+  int fr_defer;     // bn256_ctx_fr_defer_sync: Fr calls without a host-visible result do not wait for the stream
   int force_split;  // enqueue the split-sort kernels (set after a call met an oversized group, cleared after one that did not)
   int used_split;   // whether the pipeline enqueued last had them
   // bn256_msm_submit / bn256_msm_wait: each lane is a whole child context (own stream, workspaces,
@@ -419,6 +420,13 @@ extern "C" int bn256_ctx_set_phase_timing(bn256_ctx* ctx, int on) {
   if (!ctx) return BN256_EINVAL;
   for (int s = 0; s < ctx->nshard; s++) ctx->shard[s]->phase_timing = on != 0;
   ctx->phase_timing = on != 0;
+  return BN256_OK;
+}
+
+extern "C" int bn256_ctx_fr_defer_sync(bn256_ctx* ctx, int on) {
+  if (!ctx) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
+  ctx->fr_defer = on != 0;
   return BN256_OK;
 }
 
@@ -889,11 +897,17 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   // lets a pass grow to 9/8 of the chunk (its groups then average 30 k of the 32 k records pass B sorts in
   // LDS): 2^20 + 9 points (the BP++ commitments' HVec, go/bppp/docs_test.go:560-564) are one pass, not a
   // full one plus a 9-point one that pays every kernel's fixed cost again.
-  const size_t pass_max = wide ? chunk + chunk / 8 : chunk;
+  // Table-less calls: passes of at most 2^20 points.  A signed-reduced scalar is below 2^254.2, so the top one of
+  // the 16 windows holds 14.2 bits: its n digits land in 36 of that window's 64 sort groups, n / 36 each, and
+  // beyond 36 x 32768 = 1.18 M points those groups outgrow pass B's LDS -- the call then ran TWICE (oversized flag,
+  // retry with the split-sort kernels, which stayed on for the lane's next call as well): the 1.57 M-point X
+  // commitment of a 2^20 WNLA's first round paid ~1.3 ms for it.  Two balanced passes into the same 16 bucket
+  // sets (add_prev) cost one more sort and fix-up instead.
+  const size_t pass_max = wide ? chunk + chunk / 8 : (precomp ? chunk : std::min(chunk, (size_t)1 << 20));
   auto pass_len = [&](const msm_src& t) -> size_t {  // points per pass of a term
     const size_t n_term = t.n;
     const bool split_upload = t.host_sc && precomp && n_term >= ((size_t)1 << 20);  // below, two passes cost what they hide
-    if (!precomp || (n_term <= pass_max && !split_upload)) return n_term;
+    if (n_term <= pass_max && !split_upload) return n_term;
     const size_t np = std::max<size_t>((n_term + pass_max - 1) / pass_max, split_upload ? 2 : 1);
     const size_t len = ((n_term + np - 1) / np + SORT2_TILE - 1) / SORT2_TILE * SORT2_TILE;
     return std::min(len, pass_max);
@@ -2257,7 +2271,81 @@ extern "C" int bn256_fr_fold_multi(bn256_ctx* ctx, int k, const bn256_frvec* con
                          (u32)n_b[i], (u32)stride[i], fr_arg_canon(fr_arg_from_be(s_a_be + 32 * i)),
                          fr_arg_canon(fr_arg_from_be(s_b_be + 32 * i)), out[i]->d, (u32)n);
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);  // one wait for all k folds
+  hipError_t e = ctx->fr_defer ? hipGetLastError() : hipStreamSynchronize(ctx->stream);  // one wait for all k folds
+  if (e != hipSuccess) {
+    ctx_note_hip(e, __LINE__);
+    undo();
+    return BN256_EHIP;
+  }
+  return BN256_OK;
+}
+
+static bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+
+extern "C" int bn256_fr_tensor_step_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* w, int layout,
+                                          const uint8_t* lo_be, const uint8_t* hi_be, bn256_frvec** out) {
+  if (!ctx || k < 0 || (layout != 0 && layout != 1) || (k && (!w || !lo_be || !hi_be || !out))) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
+  int rc;
+  for (int i = 0; i < k; i++) {
+    out[i] = nullptr;
+    if (w[i] && (!is_pow2(w[i]->n) || w[i]->n >= (1u << 30))) return BN256_EINVAL;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int i = 0; i < k; i++) {
+    const size_t len = w[i] ? w[i]->n : 1;
+    if (!(out[i] = frvec_alloc(2 * len, &rc))) {
+      for (int j = 0; j < i; j++) {
+        bn256_fr_free(ctx, out[j]);
+        out[j] = nullptr;
+      }
+      return rc;
+    }
+    hipLaunchKernelGGL(k_fr_tensor_step, dim3(nblocks(2 * len, 256)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)(w[i] ? w[i]->d : nullptr), (u32)len, (u32)layout,
+                       fr_arg_canon(fr_arg_from_be(lo_be + 32 * i)), fr_arg_canon(fr_arg_from_be(hi_be + 32 * i)), out[i]->d);
+  }
+  HIPCHK(hipGetLastError());
+  return BN256_OK;  // no wait: the only readers are later calls on this context, on the same stream
+}
+
+extern "C" int bn256_fr_tensor_expand_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* v, const size_t* n_out,
+                                            const bn256_frvec* const* w, int layout, const int* sel, const int* swap,
+                                            const uint8_t* s_clear_be, const uint8_t* s_set_be, bn256_frvec** out) {
+  if (!ctx || k < 0 || (layout != 0 && layout != 1) ||
+      (k && (!v || !n_out || !w || !sel || !swap || !s_clear_be || !s_set_be || !out)))
+    return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
+  int rc;
+  for (int i = 0; i < k; i++) {
+    out[i] = nullptr;
+    if (!v[i] || sel[i] < 0 || sel[i] > 30) return BN256_EINVAL;
+    if (n_out[i] >= (1ull << 31)) return BN256_ETOOLARGE;
+    if (w[i] && !is_pow2(w[i]->n)) return BN256_EINVAL;
+    // half folds need whole blocks: n_out = n_t * 2^t with n_t a power of two
+    if (layout == 1 && n_out[i] && (!is_pow2(n_out[i]) || (w[i] && w[i]->n > n_out[i]))) return BN256_EINVAL;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  auto undo = [&]() {
+    for (int i = 0; i < k; i++) {
+      if (out[i]) bn256_fr_free(ctx, out[i]);
+      out[i] = nullptr;
+    }
+  };
+  for (int i = 0; i < k; i++) {
+    if (!(out[i] = frvec_alloc(n_out[i], &rc))) {
+      undo();
+      return rc;
+    }
+    if (!n_out[i]) continue;
+    u32 t = 0;
+    while (w[i] && ((size_t)1 << t) < w[i]->n) t++;
+    hipLaunchKernelGGL(k_fr_tensor_expand, dim3(nblocks(n_out[i], 256)), dim3(256), 0, ctx->stream, (const uint8_t*)v[i]->d,
+                       (u32)v[i]->n, (u32)n_out[i], t, (u32)layout, (u32)sel[i], (u32)(swap[i] != 0),
+                       (const uint8_t*)(w[i] ? w[i]->d : nullptr), fr_arg_canon(fr_arg_from_be(s_clear_be + 32 * i)),
+                       fr_arg_canon(fr_arg_from_be(s_set_be + 32 * i)), out[i]->d);
+  }
+  hipError_t e = ctx->fr_defer ? hipGetLastError() : hipStreamSynchronize(ctx->stream);  // one wait for all k vectors
   if (e != hipSuccess) {
     ctx_note_hip(e, __LINE__);
     undo();

@@ -965,6 +965,87 @@ Point devMsmWait(bn256_ctx* ctx, int ticket) {
   return out;
 }
 
+// The scalars of commitments over generators that are no longer folded (bn256_fr_tensor_step_multi /
+// bn256_fr_tensor_expand_multi): out_i[m] = w_i[j] * s_i(I) * v_i[I ^ (swap_i << sel_i)]; one device call for all
+// of a round's vectors.  w = nullptr: no round since the freeze yet.
+struct ExpandArg {
+  const DevFr* v;
+  size_t n_out;
+  const DevFr* w;
+  int sel;
+  bool swap;
+  Fr s_clear, s_set;
+};
+std::vector<DevFr> devTensorExpand(bn256_ctx* ctx, const std::vector<ExpandArg>& a, int layout) {
+  const size_t k = a.size();
+  std::vector<const bn256_frvec*> v(k), w(k);
+  std::vector<size_t> n_out(k);
+  std::vector<int> sel(k), swap(k);
+  std::vector<uint8_t> sc(32 * k), ss(32 * k);
+  for (size_t i = 0; i < k; i++) {
+    v[i] = a[i].v->h;
+    w[i] = a[i].w && a[i].w->h ? a[i].w->h : nullptr;
+    n_out[i] = a[i].n_out;
+    sel[i] = a[i].sel;
+    swap[i] = a[i].swap;
+    fr_to_be(&sc[32 * i], a[i].s_clear);
+    fr_to_be(&ss[32 * i], a[i].s_set);
+  }
+  std::vector<bn256_frvec*> out(k, nullptr);
+  chk(bn256_fr_tensor_expand_multi(ctx, (int)k, v.data(), n_out.data(), w.data(), layout, sel.data(), swap.data(), sc.data(),
+                                   ss.data(), out.data()));
+  std::vector<DevFr> r;
+  for (size_t i = 0; i < k; i++) r.emplace_back(ctx, out[i]);
+  return r;
+}
+// k * g for ONE point g and many k (wnla's v_x g and v_r g, two per round, docs_test.go:1312,1318): signed-free
+// 4-bit windows over the two GLV halves, table d * 16^w * g for w < 33, d < 16 (495 additions to build, once),
+// then 66 additions per product instead of scalarMult's 130 doublings + ~97 additions.
+class FixedBase {
+  std::vector<hostg1::Pt> T;  // [w][d - 1]
+  bool inf = false;
+
+ public:
+  explicit FixedBase(const Point& g) {
+    hostg1::Pt b = pt_load(g);
+    inf = hostg1::is_inf(b);
+    if (inf) return;
+    T.resize(33 * 15);
+    for (int w = 0; w < 33; w++) {
+      T[15 * w] = b;
+      for (int d = 2; d <= 15; d++) T[15 * w + d - 1] = hostg1::padd(T[15 * w + d - 2], b);
+      b = hostg1::padd(T[15 * w + 14], b);  // 16 * b
+    }
+  }
+  Point mul(const Fr& k) const {
+    if (inf) return pt_from(hostg1::infinity());
+    static const hostg1::Fp beta = [] {
+      const uint64_t w[4] = {0xb9ff3815a6c2a92eULL, 0x877db38fb92fa161ULL, 0xcb5601bf83f4fcf8ULL, 0};
+      return hostg1::from_raw(w);
+    }();
+    uint8_t kb[32], k1b[32], k2b[32];
+    int n1 = 0, n2 = 0;
+    fr_to_be(kb, k);
+    if (int rc = bn256_glv_split(kb, k1b, &n1, k2b, &n2)) throw std::runtime_error(bn256_strerror(rc));
+    const hostg1::Fp zero = {{0, 0, 0, 0}};
+    hostg1::Pt acc = hostg1::infinity();
+    for (int h = 0; h < 2; h++) {
+      const uint8_t* kk = h ? k2b : k1b;  // big-endian magnitude below 2^130
+      const bool neg = h ? n2 != 0 : n1 != 0;
+      for (int w = 0; w < 33; w++) {
+        const int byte = 31 - w / 2;
+        const unsigned d = (w & 1) ? (kk[byte] >> 4) : (kk[byte] & 15);
+        if (!d) continue;
+        hostg1::Pt t = T[15 * w + d - 1];
+        if (h) t.x = hostg1::mul(t.x, beta);
+        if (neg) t.y = hostg1::sub(zero, t.y);
+        acc = hostg1::padd(acc, t);
+      }
+    }
+    return pt_from(acc);
+  }
+};
+
 // One host thread that runs small jobs in order, beside the caller: wnla's running commitment
 // C' = C + y X + (y^2 - 1) R (two host scalar multiplications per round, ~85 us) is needed only by the
 // final check, so it does not have to sit between a round's last wait and the next round's submits.
@@ -1052,6 +1133,45 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
   };
   const bool per_round = getenv("BP_PROFILE") && atoi(getenv("BP_PROFILE")) >= 2;
   double prev[6] = {0, 0, 0, 0, 0, 0};
+  // Small rounds: once both generator vectors are down to kFreeze points they are no longer folded.  A fold is
+  // a latency chain of ~130 doublings per output, ~0.45 ms whatever the length, and the next round cannot
+  // start without it: 11 of the 19 rounds at |l| = 2^20 were exactly that long.  Instead the round-t generators
+  // stay what they are, G_t[I] = sum_j W(j) G_f[2^t I + j] (W the tensor of the rounds' fold scalars), and
+  // every later commitment <G_t, a> is taken as <G_f, W (x) a>: one MSM over the frozen vector with scalars
+  // that a small Fr kernel expands (bn256_fr_tensor_expand_multi).  The same group elements, X and R byte for
+  // byte.  BP_WNLA_FREEZE=<points> moves the threshold (0: fold to the end, as the reference does).
+  static const size_t kFreeze =
+      std::min<size_t>(getenv("BP_WNLA_FREEZE") ? (size_t)strtoull(getenv("BP_WNLA_FREEZE"), nullptr, 10) : 4096, (size_t)1 << 22);
+  bool frozen = false;
+  int ft = 0;                    // rounds since the freeze
+  DevFr wG, wH;                  // the tensor of the fold scalars of those rounds: G' = rho*G0 + y*G1, H' = H0 + y*H1
+  const FixedBase gTable(g);     // v_x g and v_r g of every round (docs_test.go:1312,1318)
+  // Frozen rounds run TWO at a time: the protocol is interactive (y comes from the reader, docs_test.go:1294, not
+  // from a hash of X and R), so nothing of round k + 1 -- its scalar folds, inner products, expanded vectors --
+  // needs X_k or R_k, only the running C' does, and that is read at the very end.  A round's two MSMs take two of
+  // the four lanes; while they run the host prepares and submits the next round's on the other two, and only then
+  // collects.  Every vector a submitted MSM may still read -- and every vector whose release would wait for the
+  // lanes (bn256_fr_free does) -- stays in the round's record until its results are in.
+  struct PendingRound {
+    int tx, tr;
+    Point gx, gr;
+    Fr y;
+    std::vector<DevFr> keep;
+  };
+  std::deque<PendingRound> pending;
+  auto collect = [&]() {
+    PendingRound pr = std::move(pending.front());
+    pending.pop_front();
+    Point X = pointAdd(pr.gx, devMsmWait(ctx, pr.tx));
+    Point R = pointAdd(pr.gr, devMsmWait(ctx, pr.tr));
+    res.X.push_back(X);
+    res.R.push_back(R);
+    const Fr y = pr.y;
+    chain.push([&C, X, R, y] {  // C is read again only after chain.wait()
+      Point C_ = pointAdd(C, scalarMult(X, y));
+      C = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
+    });
+  };
   for (;;) {
     if (per_round) {  // BP_PROFILE=2: the split of every round
       if (!res.X.empty())
@@ -1063,9 +1183,18 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     Fr roinv = fr_inv(ro);
     lap(PF_OTHER);
     if (l.n + n.n < 6) {
+      while (!pending.empty()) collect();
+      lap(PF_MSM);
       Fr v = add(devDot(ctx, c, whole(c.n), l, whole(l.n), nullptr), devDot(ctx, n, whole(n.n), n, whole(n.n), &mu));
-      Point Cc = pointAdd(scalarMult(g, v), devMsmFused(ctx, {{&H, whole(H.n), &l, whole(l.n), nullptr},
-                                                                 {&G, whole(G.n), &n, whole(n.n), nullptr}}));
+      Point Cc;
+      if (frozen) {
+        std::vector<DevFr> e = devTensorExpand(ctx, {{&l, H.n, &wH, 0, false, kFrOne, kFrOne},
+                                                     {&n, G.n, &wG, 0, false, kFrOne, kFrOne}}, 0);
+        Cc = pointAdd(scalarMult(g, v), devMsmFused(ctx, {{&H, whole(H.n), &e[0], whole(e[0].n), nullptr},
+                                                           {&G, whole(G.n), &e[1], whole(e[1].n), nullptr}}));
+      } else
+        Cc = pointAdd(scalarMult(g, v), devMsmFused(ctx, {{&H, whole(H.n), &l, whole(l.n), nullptr},
+                                                           {&G, whole(G.n), &n, whole(n.n), nullptr}}));
       res.l = l.download();
       res.n = n.download();
       chain.wait();
@@ -1076,8 +1205,74 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     }
     Fr y = valuesPP(rd, 1)[0];
     View c0 = evens(c.n), c1 = odds(c.n), l0 = evens(l.n), l1 = odds(l.n), n0 = evens(n.n), n1 = odds(n.n);
-    View G0 = evens(G.n), G1 = odds(G.n), H0 = evens(H.n), H1 = odds(H.n);
     Fr mu2 = mul(mu, mu);
+    if (!frozen && kFreeze && G.n <= kFreeze && H.n <= kFreeze) {
+      frozen = true;
+    }
+    if (frozen) {
+      // X = v_x g + <H0, l1> + <H1, l0> + rho <G0, n1> + rho^-1 <G1, n0>,  R = v_r g + <H1, l1> + <G1, n1>
+      // (docs_test.go:1312-1320) over the frozen H, G: four expanded scalar vectors, one call.  The round's three
+      // groups of Fr kernels -- expanded vectors, next round's c, l, n, the five inner products -- are enqueued
+      // back to back and waited for ONCE (the inner products' result is the only thing the host reads).
+      chk(bn256_ctx_fr_defer_sync(ctx, 1));
+      struct DeferOff {
+        bn256_ctx* c;
+        ~DeferOff() { (void)bn256_ctx_fr_defer_sync(c, 0); }
+      } defer_off{ctx};
+      std::vector<DevFr> e = devTensorExpand(ctx, {{&l, H.n, &wH, 0, true, kFrOne, kFrOne},
+                                                   {&n, G.n, &wG, 0, true, ro, roinv},
+                                                   {&l, H.n, &wH, 0, false, kFrZero, kFrOne},
+                                                   {&n, G.n, &wG, 0, false, kFrZero, kFrOne}}, 0);
+      DevFr c_, l_, n_;
+      devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
+      lap(PF_FRFOLD);
+      Fr d5[5];
+      devDotMulti(ctx, {{&n, n0, &n, n1, &mu2}, {&c, c0, &l, l1, nullptr}, {&c, c1, &l, l0, nullptr},
+                        {&n, n1, &n, n1, &mu2}, {&c, c1, &l, l1, nullptr}}, d5);  // waits: e, c_, l_, n_ are complete
+      Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv)), add(d5[1], d5[2]));
+      Fr vr = add(d5[3], d5[4]);
+      lap(PF_DOT);
+      while (pending.size() >= BN256_ASYNC_LANES / 2) collect();  // two lanes per round
+      lap(PF_MSM);
+      PendingRound pr;
+      pr.y = y;
+      pr.tx = devMsmFusedSubmit(ctx, {{&H, whole(H.n), &e[0], whole(e[0].n), nullptr}, {&G, whole(G.n), &e[1], whole(e[1].n), nullptr}});
+      pr.tr = devMsmFusedSubmit(ctx, {{&H, whole(H.n), &e[2], whole(e[2].n), nullptr}, {&G, whole(G.n), &e[3], whole(e[3].n), nullptr}});
+      lap(PF_MSM);
+      pr.gx = gTable.mul(vx);
+      pr.gr = gTable.mul(vr);
+      lap(PF_HOSTPT);
+      // this round's vectors retire with its record (their release would wait for the lanes)
+      for (DevFr& x : e) pr.keep.push_back(std::move(x));
+      pr.keep.push_back(std::move(c));
+      pr.keep.push_back(std::move(l));
+      pr.keep.push_back(std::move(n));
+      DevFr wg_old = std::move(wG), wh_old = std::move(wH);
+      {
+        const bn256_frvec* w[2] = {wg_old.h, wh_old.h};
+        uint8_t lo[64], hi[64];
+        fr_to_be(lo, ro);
+        fr_to_be(lo + 32, kFrOne);
+        fr_to_be(hi, y);
+        fr_to_be(hi + 32, y);
+        bn256_frvec* out[2] = {nullptr, nullptr};
+        chk(bn256_fr_tensor_step_multi(ctx, 2, w, 0, lo, hi, out));
+        wG = DevFr(ctx, out[0]);
+        wH = DevFr(ctx, out[1]);
+      }
+      pr.keep.push_back(std::move(wg_old));
+      pr.keep.push_back(std::move(wh_old));
+      pending.push_back(std::move(pr));
+      ft++;
+      c = std::move(c_);
+      ro = mu;
+      mu = mu2;
+      l = std::move(l_);
+      n = std::move(n_);
+      lap(PF_OTHER);
+      continue;
+    }
+    View G0 = evens(G.n), G1 = odds(G.n), H0 = evens(H.n), H1 = odds(H.n);
     // H_ = H0 (+) y*H1 ; G_ = ro*G0 (+) y*G1   (docs_test.go:1325-1326), ragged folds on device.  Neither
     // needs anything of this round but y and ro, and y comes from the reader before X and R exist
     // (docs_test.go:1294), so both folds -- ~0.5 ms latency chains of ~130 doublings whatever the length --
@@ -1107,7 +1302,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv)), add(d5[1], d5[2]));
     Fr vr = add(d5[3], d5[4]);
     lap(PF_DOT);
-    Point gx = scalarMult(g, vx), gr = scalarMult(g, vr);  // under the MSMs, which the lanes' threads are running
+    Point gx = gTable.mul(vx), gr = gTable.mul(vr);  // under the MSMs, which the lanes' threads are running
     lap(PF_HOSTPT);
     Point mx = devMsmWait(ctx, tx);
     Point mr = devMsmWait(ctx, tr);

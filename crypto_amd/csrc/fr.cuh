@@ -223,6 +223,50 @@ __global__ void __launch_bounds__(256) k_fr_sum(fr_dot_batch batch, uint8_t* __r
   if (threadIdx.x == 0) fr_store_be(out_be + 32 * (size_t)blockIdx.x, lds[0]);
 }
 
+// Scalar vectors for MSMs over generators that were NOT folded.  After t folding rounds G' = lo G_a (+) hi G_b
+// the round-t generator is a fixed combination of the frozen ones, G_t[I] = sum_j W(j) G_0[m(I, j)], with W the
+// tensor of the rounds' fold scalars, so <G_t, a> = <G_0, W (x) a>: one MSM over the frozen vector instead of t
+// latency-bound generator folds.  Two index layouts:
+//   layout 0, even / odd folds (WNLA, go/bppp/docs_test.go:1325-1326: G'[i] = lo G[2i] + hi G[2i+1]):
+//             m = 2^t I + j, a new round is the new TOP bit of j;
+//   layout 1, half folds (inner-product argument, go/bp/main.go:355-356: G'[i] = lo G[i] + hi G[i + n/2]):
+//             m = I + n_t j, a new round is the new LOW bit of j.
+// k_fr_tensor_step: w' = the weights after one more round (w = [1] before the first).
+__global__ void __launch_bounds__(256) k_fr_tensor_step(const uint8_t* __restrict__ w, u32 len, u32 layout, fr_arg lo,
+                                                        fr_arg hi, uint8_t* __restrict__ out) {
+  u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= 2 * len) return;
+  const u32 b = layout ? (m & 1u) : (m >= len ? 1u : 0u), j = layout ? (m >> 1) : (b ? m - len : m);
+  const fr f = fr_to_mont(fr_from_arg(b ? hi : lo));
+  fr x;
+  if (w) {
+    x = fr_load_be(w + (size_t)j * 32);
+  } else {
+    x = fr_zero();
+    x.w[0] = 1;
+  }
+  fr_store_be(out + (size_t)m * 32, fr_mont(x, f));
+}
+// out[m] = w[j] * s(I) * v[I ^ (swap << sel)], with (I, j) = (m >> t, m mod 2^t) in layout 0 and
+// (m mod n_t, m / n_t) in layout 1 (n_t = n_out >> t, a power of two there); s(I) = s_set when bit `sel` of I is
+// set, s_clear otherwise; a source index past n_v reads 0 (the BP++ zero padding).  swap = 1 pairs each half
+// with the OTHER half's scalars (<H0, l1> + <H1, l0>; <G[n1:], a[:n1]>).
+__global__ void __launch_bounds__(256) k_fr_tensor_expand(const uint8_t* __restrict__ v, u32 n_v, u32 n_out, u32 t,
+                                                          u32 layout, u32 sel, u32 swap, const uint8_t* __restrict__ w,
+                                                          fr_arg s_clear, fr_arg s_set, uint8_t* __restrict__ out) {
+  u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_out) return;
+  const u32 nI = n_out >> t;
+  const u32 I = layout ? (m & (nI - 1u)) : (m >> t), j = layout ? (m / nI) : (m & ((1u << t) - 1u));
+  const u32 src = I ^ (swap << sel);
+  fr r = fr_zero();
+  if (src < n_v) {
+    r = fr_mont(fr_load_be(v + (size_t)src * 32), fr_to_mont(fr_from_arg(((I >> sel) & 1u) ? s_set : s_clear)));
+    if (w) r = fr_mont(r, fr_to_mont(fr_load_be(w + (size_t)j * 32)));
+  }
+  fr_store_be(out + (size_t)m * 32, r);
+}
+
 // Gathers one (points view, scalars view) segment into contiguous arrays so that several
 // segments become ONE MSM: dst_pts[i] = src_pts[i*pt_stride], dst_sc[i] = scale * src_sc[i*sc_stride]
 // (scale optional).  <rho * n1, G0> of the WNLA round (go/bppp/docs_test.go:1296-1306) is a

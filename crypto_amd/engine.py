@@ -349,6 +349,31 @@ class Engine:
                                                b"".join(int(it[7]).to_bytes(32, "big") for it in items), outs))
         return [FrVec(self, C.c_void_p(outs[j])) for j in range(k)]
 
+    def fr_tensor_step(self, items: Sequence[tuple], layout: int = 0) -> list[FrVec]:
+        """items: (w or None, lo, hi) -- the fold-scalar tensor after one more round (bn256_fr_tensor_step_multi)."""
+        k = len(items)
+        m = max(k, 1)
+        outs = (C.c_void_p * m)()
+        self._chk(self.lib.bn256_fr_tensor_step_multi(
+            self.ctx, k, (C.c_void_p * m)(*[(it[0].h if it[0] is not None else None) for it in items]), layout,
+            b"".join(int(it[1]).to_bytes(32, "big") for it in items), b"".join(int(it[2]).to_bytes(32, "big") for it in items),
+            outs))
+        return [FrVec(self, C.c_void_p(outs[j])) for j in range(k)]
+
+    def fr_tensor_expand(self, items: Sequence[tuple], layout: int = 0) -> list[FrVec]:
+        """items: (v, n_out, w or None, sel, swap, s_clear, s_set) -- out[m] = w[j] * s(I) * v[I ^ (swap << sel)]: the scalars
+        of an MSM over unfolded generators (bn256_fr_tensor_expand_multi)."""
+        k = len(items)
+        m = max(k, 1)
+        outs = (C.c_void_p * m)()
+        self._chk(self.lib.bn256_fr_tensor_expand_multi(
+            self.ctx, k, (C.c_void_p * m)(*[it[0].h for it in items]), (C.c_size_t * m)(*[it[1] for it in items]),
+            (C.c_void_p * m)(*[(it[2].h if it[2] is not None else None) for it in items]), layout,
+            (C.c_int * m)(*[int(it[3]) for it in items]), (C.c_int * m)(*[int(it[4]) for it in items]),
+            b"".join(int(it[5]).to_bytes(32, "big") for it in items), b"".join(int(it[6]).to_bytes(32, "big") for it in items),
+            outs))
+        return [FrVec(self, C.c_void_p(outs[j])) for j in range(k)]
+
     def msm_fr(self, bases: Bases, off: int, stride: int, n: int, v: FrVec, v_off: int = 0, v_stride: int = 1) -> bytes:
         out = C.create_string_buffer(64)
         self._chk(self.lib.bn256_msm_fr(self.ctx, bases.h, off, stride, n, v.h, v_off, v_stride, out))

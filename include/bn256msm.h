@@ -259,6 +259,41 @@ int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const
                        const size_t* n_a, const bn256_frvec* const* b, const size_t* b_off, const size_t* b_stride,
                        const size_t* n_b, const uint8_t* const* mu_be, uint8_t* out_be);
 
+/* Scalar vectors for MSMs over generators that were NOT folded.  After t folding rounds G' = lo G_a (+) hi G_b
+ * (WNLA: G'[i] = rho G[2i] + y G[2i+1], go/bppp/docs_test.go:1325-1326; inner-product argument:
+ * G'[i] = x^-1 G[i] + x G[i + n/2], go/bp/main.go:355-356) the round-t generator is a fixed combination of the
+ * frozen ones, G_t[I] = sum_j W(j) G_0[m(I, j)], W the tensor of the rounds' fold scalars, so every later
+ * commitment <G_t, a> equals <G_0, W (x) a>: ONE MSM over the frozen vector in place of t generator folds --
+ * each a latency chain of ~130 doublings per output, ~0.45 ms whatever the length, which is what the small
+ * rounds of a proof spent their time on.  Same group elements, same transcript; the reference folds (on a CPU
+ * it has no reason not to).  layout 0: even / odd folds, m = 2^t I + j; layout 1: half folds, m = I + n_t j
+ * (n_out must then be a power of two).
+ *   bn256_fr_tensor_step_multi    out_i = the weights W after one more round with scalars (lo_i, hi_i); w_i = NULL
+ *                                 stands for the one-element vector [1].  Enqueued, not waited for: its only
+ *                                 readers are later calls on this context.
+ *   bn256_fr_tensor_expand_multi  out_i[m] = w_i[j] * s_i(I) * v_i[I ^ (swap_i << sel_i)], m < n_out_i, with
+ *                                 s_i(I) = s_set_i if bit sel_i of I is set, else s_clear_i (k * 32 bytes each; a
+ *                                 zero scalar blanks that half); swap_i = 1 pairs each half with the other
+ *                                 half's scalars (<H0, l1> + <H1, l0>, docs_test.go:1312-1316; <G[n1:], a[:n1]>,
+ *                                 go/bp/main.go:340); a source index past the end of v_i reads 0 (the BP++
+ *                                 zero padding).  sel_i = 0 is the even / odd split, sel_i = log2(n_t) - 1 the
+ *                                 lower / upper half.  One device call, one wait.
+ * The vectors live on devices[0] of a multi-device context. */
+int bn256_fr_tensor_step_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* w, int layout, const uint8_t* lo_be,
+                               const uint8_t* hi_be, bn256_frvec** out);
+int bn256_fr_tensor_expand_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* v, const size_t* n_out,
+                                 const bn256_frvec* const* w, int layout, const int* sel, const int* swap,
+                                 const uint8_t* s_clear_be, const uint8_t* s_set_be, bn256_frvec** out);
+
+/* Batching of small Fr calls.  A proof's small rounds are a handful of tiny kernels each (three vector folds, four
+ * expanded vectors, five inner products: go/bppp/docs_test.go:1297-1334), and a wait per call (~25 us) was
+ * most of such a round.  While on, the calls that return no host-visible value -- bn256_fr_fold(_multi),
+ * bn256_fr_tensor_expand_multi -- return as soon as their kernels are enqueued; the results are defined for
+ * every later call on this context at once (same stream), and for everyone else -- the lanes of the submit calls
+ * included -- after the next call that does wait (bn256_fr_dot(_multi), bn256_fr_download, bn256_ctx_drain, any
+ * blocking MSM).  Off by default. */
+int bn256_ctx_fr_defer_sync(bn256_ctx* ctx, int on);
+
 /* bn256_msm over views: sum_i v[v_off + i*v_stride] * b[off + i*stride], scalars never leave
  * the device (vectorPointScalarMul on reducePoints / reduceVector halves). */
 int bn256_msm_fr(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t stride, size_t n, const bn256_frvec* v,

@@ -255,3 +255,87 @@ def test_wl_times_w_of_test_ac3_on_the_device_matches_the_reference_held_vector(
     assert got == want
     hw.free()
     hm.free()
+
+
+def test_tensor_expand_is_the_folded_generators_msm(eng, orc):
+    """bn256_fr_tensor_step_multi / _expand_multi: the scalars W (x) a of an MSM over generators that were not folded.
+    Checked (i) element by element against the formula in Python, and (ii) as group elements: t rounds of the WNLA
+    fold G' = rho*G0 + y*G1 (go/bppp/docs_test.go:1325-1326) on the device, then <G_t, a>, against ONE MSM over
+    the unfolded G with the expanded scalars -- including a ragged length and both pairings (swap, odd half only)."""
+    rng = random.Random(77)
+    n0, t = 45, 3                                     # 45 -> 23 -> 12 -> 6 virtual generators
+    los, his = [rng.randrange(1, N) for _ in range(t)], [rng.randrange(1, N) for _ in range(t)]
+    nv = (n0 + (1 << t) - 1) >> t
+    a = _vals(rng, nv)
+    s_even, s_odd = rng.randrange(N), rng.randrange(N)
+    hv = eng.fr_upload(a)
+    w, ws = None, []
+    for s in range(t):
+        w = eng.fr_tensor_step([(w, los[s], his[s])])[0]
+        ws.append(w)
+    W = [1]
+    for s in range(t):
+        W = [x * los[s] % N for x in W] + [x * his[s] % N for x in W]
+    assert w.download() == W
+    outs = eng.fr_tensor_expand([(hv, n0, w, 0, 0, 1, 1), (hv, n0, w, 0, 1, s_even, s_odd), (hv, n0, w, 0, 0, 0, 1),
+                                 (hv, n0 - 7, w, 0, 1, 1, 0), (hv, nv, None, 0, 1, 1, 1)])
+
+    def want(n_out, swap, se, so):
+        r = []
+        for m in range(n_out):
+            I, src = m >> t, (m >> t) ^ swap
+            r.append(W[m & ((1 << t) - 1)] * (so if I & 1 else se) * (a[src] if src < nv else 0) % N)
+        return r
+
+    got = [o.download() for o in outs]
+    assert got[0] == want(n0, 0, 1, 1)
+    assert got[1] == want(n0, 1, s_even, s_odd)
+    assert got[2] == want(n0, 0, 0, 1)
+    assert got[3] == want(n0 - 7, 1, 1, 0)
+    assert got[4] == [a[i ^ 1] if (i ^ 1) < nv else 0 for i in range(nv)]      # no weights: t = 0
+    # (ii) the folds themselves
+    g = eng.random_bases(0x7E50, n0)
+    cur, owned = g, []
+    for s in range(t):
+        n = len(cur)
+        cur = eng.fold2(cur, 0, (n + 1) // 2, cur, 1, n // 2, los[s], his[s], stride=2)
+        owned.append(cur)
+    assert len(cur) == nv
+    assert eng.msm(cur, a) == eng.msm_fr(g, 0, 1, n0, outs[0])
+    # <G_t odd half, a odd half> (the R commitment's shape) and the swapped pairing (X's): as MSMs over strided views
+    assert eng.msm_multi([(cur, 1, a[1::2], 2)]) == eng.msm_fr(g, 0, 1, n0, outs[2])
+    ev_a, od_a = a[0::2], a[1::2]
+    lhs = eng.msm_multi([(cur, 0, [x * s_even % N for x in od_a], 2), (cur, 1, [x * s_odd % N for x in ev_a], 2)])
+    assert lhs == eng.msm_fr(g, 0, 1, n0, outs[1])
+    for o in outs + owned + ws + [g, hv]:
+        o.free()
+
+
+def test_tensor_expand_half_folds_of_the_inner_product_argument(eng):
+    """layout 1: G'[i] = lo*G[i] + hi*G[i + n/2] (go/bp/main.go:355-356).  After t rounds <G_t, a> and the L / R
+    shapes <G_t[n1:], a[:n1]>, <G_t[:n1], a[n1:]> (main.go:340-341) against MSMs over the unfolded G."""
+    rng = random.Random(78)
+    n0, t = 64, 3
+    los, his = [rng.randrange(1, N) for _ in range(t)], [rng.randrange(1, N) for _ in range(t)]
+    nt = n0 >> t
+    a = _vals(rng, nt)
+    hv = eng.fr_upload(a)
+    w, ws = None, []
+    for s in range(t):
+        w = eng.fr_tensor_step([(w, los[s], his[s])], layout=1)[0]
+        ws.append(w)
+    sel = nt.bit_length() - 2                          # top bit of the virtual index
+    outs = eng.fr_tensor_expand([(hv, n0, w, sel, 0, 1, 1), (hv, n0, w, sel, 1, 0, 1), (hv, n0, w, sel, 1, 1, 0)], layout=1)
+    g = eng.random_bases(0x7E51, n0)
+    cur, owned = g, []
+    for s in range(t):
+        h = len(cur) // 2
+        cur = eng.fold(cur, 0, cur, h, h, los[s], his[s])
+        owned.append(cur)
+    assert len(cur) == nt
+    n1 = nt // 2
+    assert eng.msm(cur, a) == eng.msm_fr(g, 0, 1, n0, outs[0])
+    assert eng.msm(cur, a[:n1], off=n1) == eng.msm_fr(g, 0, 1, n0, outs[1])       # upper generators, lower scalars
+    assert eng.msm(cur, a[n1:], off=0) == eng.msm_fr(g, 0, 1, n0, outs[2])        # lower generators, upper scalars
+    for o in outs + owned + ws + [g, hv]:
+        o.free()
