@@ -455,11 +455,30 @@ struct InnerProductProof {  // go/bp/main.go:253-260
   Fr A, B;
 };
 
+// Small levels of the inner-product argument run over generators that are no longer folded (see wnla below and
+// bn256_fr_tensor_expand_multi): after t levels G_t[i] = sum_j W(j) G_f[i + n_t j], W the tensor of the levels'
+// (x^-1, x) -- (x, x^-1) for H -- so every commitment of a later level is ONE MSM over the frozen G_f, H_f with
+// expanded scalars, and the two ~0.45 ms generator-fold chains per level (main.go:355-356) disappear: from the
+// prover's critical path, and from the verifier altogether (it needs only the final G[0], H[0]: the classic
+// s-vector MSM).  Same group elements, same transcript.  BP_IPA_FREEZE=<n> moves the threshold (0: always fold).
+struct DevFr;
+struct IpaFrozen;
+static size_t ipaFreeze() {
+  static const size_t v = getenv("BP_IPA_FREEZE") ? (size_t)strtoull(getenv("BP_IPA_FREEZE"), nullptr, 10) : 4096;
+  return v;
+}
+InnerProductProof innerArgProofFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, FrVec a, FrVec b,
+                                      InnerProductProof proof);
+std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, Point P,
+                                 const InnerProductProof& proof, size_t deep);
+
 // innerArgProof, go/bp/main.go:321-377 (recursion unrolled into a loop; G, H stay on device)
 InnerProductProof innerArgProof(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, FrVec a, FrVec b) {
   InnerProductProof proof;
   while (N != 1) {
     if (N % 2 != 0) throw std::runtime_error("invalid n: should be 2^x");
+    if (ipaFreeze() && (size_t)N <= ipaFreeze() && (N & (N - 1)) == 0)
+      return innerArgProofFrozen(ctx, N, std::move(G), std::move(H), U, std::move(a), std::move(b), std::move(proof));
     size_t n1 = N / 2;
     FrVec alo = slice(a, 0, n1), ahi = slice(a, n1, N), blo = slice(b, 0, n1), bhi = slice(b, n1, N);
     Fr cl = vectorMul(alo, bhi), cr = vectorMul(ahi, blo);
@@ -510,6 +529,8 @@ std::string innerArgVerify(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, cons
   while (N != 1) {
     if (N % 2 != 0) return "invalid n: should be 2^x";
     if (deep >= proof.L.size() || deep >= proof.R.size()) return "failed to verify inner argument proof";
+    if (ipaFreeze() && (size_t)N <= ipaFreeze() && (N & (N - 1)) == 0)
+      return innerArgVerifyFrozen(ctx, N, std::move(G), std::move(H), U, P, proof, deep);
     size_t n1 = N / 2;
     Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, proof.L[deep], proof.R[deep]});
     Fr xinv = fr_inv(x), x2 = mul(x, x), x2inv = fr_inv(x2);
@@ -998,6 +1019,88 @@ std::vector<DevFr> devTensorExpand(bn256_ctx* ctx, const std::vector<ExpandArg>&
   for (size_t i = 0; i < k; i++) r.emplace_back(ctx, out[i]);
   return r;
 }
+// ---- the inner-product argument over frozen generators (declared above innerArgProof)
+static int ilog2(size_t n) {
+  int r = 0;
+  while (n >>= 1) r++;
+  return r;
+}
+static void ipaStep(bn256_ctx* ctx, DevFr& wG, DevFr& wH, const Fr& x, const Fr& xinv, std::vector<DevFr>& keep) {
+  // G' = xinv*G_lo + x*G_hi ; H' = x*H_lo + xinv*H_hi   (main.go:355-356): half folds, layout 1
+  const bn256_frvec* w[2] = {wG.h, wH.h};
+  uint8_t lo[64], hi[64];
+  fr_to_be(lo, xinv);
+  fr_to_be(lo + 32, x);
+  fr_to_be(hi, x);
+  fr_to_be(hi + 32, xinv);
+  bn256_frvec* out[2] = {nullptr, nullptr};
+  chk(bn256_fr_tensor_step_multi(ctx, 2, w, 1, lo, hi, out));
+  keep.push_back(std::move(wG));
+  keep.push_back(std::move(wH));
+  wG = DevFr(ctx, out[0]);
+  wH = DevFr(ctx, out[1]);
+}
+InnerProductProof innerArgProofFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, FrVec a, FrVec b,
+                                      InnerProductProof proof) {
+  const size_t Nf = (size_t)N;  // G, H stay as they are from here on
+  DevFr wG, wH;
+  std::vector<DevFr> keep;
+  while (N != 1) {
+    const size_t n1 = (size_t)N / 2;
+    const int sel = ilog2((size_t)N) - 1;  // the top bit of a level's index: lower / upper half
+    FrVec alo = slice(a, 0, n1), ahi = slice(a, n1, N), blo = slice(b, 0, n1), bhi = slice(b, n1, N);
+    Fr cl = vectorMul(alo, bhi), cr = vectorMul(ahi, blo);
+    DevFr da(ctx, a), db(ctx, b);
+    // L = <G[n1:], a[:n1]> + <H[:n1], b[n1:]> + cl*U ; R = <G[:n1], a[n1:]> + <H[n1:], b[:n1]> + cr*U ; P = <G, a> + <H, b> + <a,b>*U
+    std::vector<DevFr> e = devTensorExpand(ctx, {{&da, Nf, &wG, sel, true, kFrZero, kFrOne}, {&db, Nf, &wH, sel, true, kFrOne, kFrZero},
+                                                 {&da, Nf, &wG, sel, true, kFrOne, kFrZero}, {&db, Nf, &wH, sel, true, kFrZero, kFrOne},
+                                                 {&da, Nf, &wG, sel, false, kFrOne, kFrOne}, {&db, Nf, &wH, sel, false, kFrOne, kFrOne}}, 1);
+    int tl = devMsmFusedSubmit(ctx, {{&G, whole(Nf), &e[0], whole(Nf), nullptr}, {&H, whole(Nf), &e[1], whole(Nf), nullptr}});
+    int tr = devMsmFusedSubmit(ctx, {{&G, whole(Nf), &e[2], whole(Nf), nullptr}, {&H, whole(Nf), &e[3], whole(Nf), nullptr}});
+    int tp = devMsmFusedSubmit(ctx, {{&G, whole(Nf), &e[4], whole(Nf), nullptr}, {&H, whole(Nf), &e[5], whole(Nf), nullptr}});
+    Point ul = scalarMult(U, cl), ur = scalarMult(U, cr), up = scalarMult(U, vectorMul(a, b));
+    Point L = pointAdd(devMsmWait(ctx, tl), ul);
+    Point R = pointAdd(devMsmWait(ctx, tr), ur);
+    Point P = pointAdd(devMsmWait(ctx, tp), up);
+    proof.L.push_back(L);
+    proof.R.push_back(R);
+    Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, L, R});
+    Fr xinv = fr_inv(x);
+    ipaStep(ctx, wG, wH, x, xinv, keep);
+    FrVec a1 = vectorAdd(vectorMulOnScalar(alo, x), vectorMulOnScalar(ahi, xinv));
+    FrVec b1 = vectorAdd(vectorMulOnScalar(bhi, x), vectorMulOnScalar(blo, xinv));
+    a = a1;
+    b = b1;
+    N = (int)n1;
+  }
+  proof.A = a[0];
+  proof.B = b[0];
+  return proof;
+}
+std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, Point P,
+                                 const InnerProductProof& proof, size_t deep) {
+  const size_t Nf = (size_t)N;
+  DevFr wG, wH;
+  std::vector<DevFr> keep;
+  while (N != 1) {
+    if (deep >= proof.L.size() || deep >= proof.R.size()) return "failed to verify inner argument proof";
+    Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, proof.L[deep], proof.R[deep]});
+    Fr xinv = fr_inv(x), x2 = mul(x, x), x2inv = fr_inv(x2);
+    ipaStep(ctx, wG, wH, x, xinv, keep);  // enqueued only: the device works beside the host's P update
+    P = pointAdd(pointAdd(scalarMult(proof.L[deep], x2), P), scalarMult(proof.R[deep], x2inv));
+    N /= 2;
+    deep++;
+  }
+  // com(G[0], H[0], a, b) + (a*b)*U  (main.go:275-279) with G[0] = <G_f, W_G>, H[0] = <H_f, W_H>: one MSM
+  FrVec one1 = {kFrOne};
+  DevFr d1(ctx, one1);
+  std::vector<DevFr> e = devTensorExpand(ctx, {{&d1, Nf, &wG, 0, false, proof.A, proof.A}, {&d1, Nf, &wH, 0, false, proof.B, proof.B}}, 1);
+  Point p = pointAdd(devMsmFused(ctx, {{&G, whole(Nf), &e[0], whole(Nf), nullptr}, {&H, whole(Nf), &e[1], whole(Nf), nullptr}}),
+                     scalarMult(U, mul(proof.A, proof.B)));
+  if (!pointEq(P, p)) return "failed to verify inner argument proof";
+  return "";
+}
+
 // k * g for ONE point g and many k (wnla's v_x g and v_r g, two per round, docs_test.go:1312,1318): signed-free
 // 4-bit windows over the two GLV halves, table d * 16^w * g for w < 33, d < 16 (495 additions to build, once),
 // then 66 additions per product instead of scalarMult's 130 doublings + ~97 additions.
