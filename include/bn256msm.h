@@ -108,9 +108,11 @@ int bn256_msm_dev(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, co
  * sums, packed results) are carved from a file-scope __device__ array of BN256_NOALLOC_SCRATCH_BYTES
  * that every GPU the library runs on holds until the process ends; its device address is resolved once
  * per device by bn256_ctx_create.  A call whose workspaces do not fit returns BN256_ESCRATCH before
- * anything is enqueued: the default 352 MiB hold a fixed-base (BN256_PRECOMPUTE) call of up to 2^20
- * points (278 MiB; 342 MiB with the split-sort workspace that skewed scalars need) and a table-less call
- * of up to 2^20 (290 MiB) -- the largest calls the entry point is meant for.  STANDING COST: the array is
+ * anything is enqueued.  What has to fit is one PASS (a fixed-base call runs in passes of <= 9/8 * 2^20
+ * points, a table-less one in passes of <= 2^20): the default 352 MiB hold a fixed-base pass of 2^20
+ * points (278 MiB; 342 MiB with the split-sort workspace that skewed scalars need) and a table-less pass of
+ * 2^20 (290 MiB), so calls of any length over the default window widths run; forced window widths whose
+ * bucket sets outgrow the array (18 bits without a table: 409 MiB) are refused.  STANDING COST: the array is
  * part of the library's code object, so EVERY process that loads the library holds it on EVERY GPU it
  * touches, whether or not this entry point is ever called; a deployment that never calls it builds with
  * -DBN256_NOALLOC_SCRATCH_BYTES=256 (every call then returns BN256_ESCRATCH), one that needs larger

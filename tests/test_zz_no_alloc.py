@@ -72,16 +72,23 @@ def test_noalloc_small_and_tableless_against_oracle(eng, orc):
         v.free()
 
 
-def test_noalloc_rejects_sizes_beyond_the_array(eng):
+def test_noalloc_rejects_sizes_beyond_the_array(eng, orc):
     import crypto_amd
     from crypto_amd.engine import BN256Error
-    n = 1 << 21   # table-less: 2^25 sort records, 400 MiB of workspaces
+    n = 1 << 21   # table-less: runs as two passes of 2^20 points, whose workspaces fit the array
     h = eng.random_bases(SEED_B, n)
     v = eng.fr_random(SEED_S, n)
     try:
-        with pytest.raises(BN256Error) as ei:
-            eng.msm_dev_noalloc(h, v.device_ptr(), n)
-        assert ei.value.code == -9 and "scratch" in str(ei.value)
+        got, want = _pair(eng, h, v, n)
+        assert got == want == orc.synth_msm_closed_form(SEED_B, SEED_S, n)
+        # 18-bit windows without a table: 15 sets of 2^17 buckets = 283 MiB of bucket sums + 126 MiB of entries
+        eng.set_tuning(window_bits=18)
+        try:
+            with pytest.raises(BN256Error) as ei:
+                eng.msm_dev_noalloc(h, v.device_ptr(), 1 << 20)
+            assert ei.value.code == -9 and "scratch" in str(ei.value)
+        finally:
+            eng.set_tuning()
         # the context is as usable as before, on both entry points
         m = 1 << 16
         assert eng.msm_dev_noalloc(h, v.device_ptr(), m) == eng.msm_dev(h, v.device_ptr(), m)
