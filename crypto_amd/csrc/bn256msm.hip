@@ -904,27 +904,45 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   // commitment of a 2^20 WNLA's first round paid ~1.3 ms for it.  Two balanced passes into the same 16 bucket
   // sets (add_prev) cost one more sort and fix-up instead.
   const size_t pass_max = wide ? chunk + chunk / 8 : (precomp ? chunk : std::min(chunk, (size_t)1 << 20));
-  auto pass_len = [&](const msm_src& t) -> size_t {  // points per pass of a term
+  // the passes of a term as start offsets (cuts[j] .. cuts[j + 1]), whole sort tiles each
+  auto plan = [&](const msm_src& t) -> std::vector<size_t> {
     const size_t n_term = t.n;
-    const bool split_upload = t.host_sc && precomp && n_term >= ((size_t)1 << 20);  // below, two passes cost what they hide
-    if (n_term <= pass_max && !split_upload) return n_term;
-    const size_t np = std::max<size_t>((n_term + pass_max - 1) / pass_max, split_upload ? 2 : 1);
-    const size_t len = ((n_term + np - 1) / np + SORT2_TILE - 1) / SORT2_TILE * SORT2_TILE;
-    return std::min(len, pass_max);
-  };
-  auto pass_count = [&](const msm_src& t) -> size_t {
-    const size_t len = pass_len(t);
-    return len ? (t.n + len - 1) / len : 1;
+    const bool split_upload = t.host_sc && precomp && n_term >= ((size_t)1 << 20);  // below, more passes cost what they hide
+    std::vector<size_t> cuts{0};
+    auto round_tile = [&](size_t v) { return std::max<size_t>(SORT2_TILE, (v + SORT2_TILE - 1) / SORT2_TILE * SORT2_TILE); };
+    if (split_upload) {
+      // Host scalars: a pass cannot start before its scalars have crossed PCIe (~0.6 ms for the 32 MiB of 2^20
+      // points), and pass j + 1's copy runs under pass j's kernels.  Two equal passes left the chip idle for the
+      // first half's copy (0.3 ms); growing passes -- 3/16, 5/16, the rest in full passes -- wait for a 0.11 ms
+      // copy and hide the others.  The gain is small (pinned 1.69 -> 1.6 ms at 2^20): every extra pass pays its
+      // fixed costs and one more addition per bucket (add_prev), DESIGN.md 6.
+      static const int fa = getenv("BN256_UPLOAD_P0") ? atoi(getenv("BN256_UPLOAD_P0")) : 3;   // sixteenths (experiments)
+      static const int fb = getenv("BN256_UPLOAD_P1") ? atoi(getenv("BN256_UPLOAD_P1")) : 5;
+      size_t p0 = std::min(round_tile(fa * (n_term / 16)), pass_max);
+      size_t p1 = fb ? std::min(round_tile(fb * (n_term / 16)), pass_max) : 0;
+      if (p0 < n_term) cuts.push_back(p0);
+      if (p1 && p0 + p1 < n_term) cuts.push_back(p0 + p1);
+    }
+    size_t at = cuts.back(), rest = n_term - at;
+    if (rest > 0) {
+      const size_t np = (rest + pass_max - 1) / pass_max;
+      const size_t len = std::min(round_tile((rest + np - 1) / np), pass_max);
+      for (size_t k = 1; k < np; k++) cuts.push_back(at + k * len);
+    }
+    cuts.push_back(n_term);
+    return cuts;
   };
   size_t npasses = 0, nmax = 0;
+  std::vector<std::vector<size_t>> plans(nsrc);
   for (int i = 0; i < nsrc; i++) {
     const msm_src& t = srcs[i];
     if (!t.n) continue;
     if ((t.b->levels > 1) != precomp || (precomp && (t.b->c != c || t.b->levels != W))) return BN256_EINVAL;
     if ((unsigned long long)t.b->n * t.b->levels >= (1ull << 31)) return BN256_ETOOLARGE;
     if (t.host_sc && t.sc_stride != 1) return BN256_EINVAL;
-    npasses += pass_count(t);
-    nmax = std::max(nmax, pass_len(t));
+    plans[i] = plan(t);
+    npasses += plans[i].size() - 1;
+    for (size_t j = 0; j + 1 < plans[i].size(); j++) nmax = std::max(nmax, plans[i][j + 1] - plans[i][j]);
   }
   const size_t nchunks = npasses;
   const unsigned long long entries_max = (unsigned long long)nmax * W;
@@ -1003,9 +1021,8 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
     return (size_t)((e + K - 1) / K);
   };
   size_t Tmax = threads_for(nmax);
-  for (int i = 0; i < nsrc; i++) {  // a short last pass has a shorter chunk length and may have more threads
-    if (srcs[i].n) Tmax = std::max(Tmax, threads_for(srcs[i].n - (pass_count(srcs[i]) - 1) * pass_len(srcs[i])));
-  }
+  for (int i = 0; i < nsrc; i++)  // a shorter pass has a shorter chunk length and may have more threads
+    for (size_t j = 0; j + 1 < plans[i].size(); j++) Tmax = std::max(Tmax, threads_for(plans[i][j + 1] - plans[i][j]));
   if ((rc = ws_reserve(ctx, WS_SVAL, entries_max * 4))) return rc;
   if ((rc = ws_reserve(ctx, WS_SKEY, nbt * 4))) return rc;  // heavy-bucket queue
   if ((rc = ws_reserve(ctx, WS_HEAVYTMP, (size_t)HEAVY_SLOTS * HEAVY_PARTS * sizeof(xyzz_mem)))) return rc;
@@ -1056,7 +1073,8 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
    const bn256_bases* b = t.b;
    const size_t stride = t.stride, sc_stride = t.sc_stride;
    const u32 top_scale = precomp ? b->top_scale : 1u;
-   const size_t np_t = pass_count(t), len_t = pass_len(t);
+   const std::vector<size_t>& cuts = plans[si];
+   const size_t np_t = cuts.size() - 1;
    // the upload of pass j's scalars (host_sc terms): issued once, at the latest when the pass starts
    size_t uploaded = 0;
    auto upload_pass = [&](size_t j) -> int {
@@ -1065,17 +1083,20 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
        HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
        for (auto& e : ctx->ev_copy) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
      }
-     const size_t first = j * len_t, len = std::min(len_t, t.n - first);
+     const size_t first = cuts[j], len = cuts[j + 1] - first;
+     // the call's very first copy has nothing to hide behind: on the compute stream itself, so that the first
+     // kernel follows it directly (an event between two streams costs ~50 us before the dependent kernel starts)
+     const bool inline_copy = ch == 0 && j == 0;
      HIPCHK(hipMemcpyAsync((uint8_t*)t.sc + first * 32, t.host_sc + first * 32, len * 32, hipMemcpyHostToDevice,
-                           ctx->copy_stream));
-     HIPCHK(hipEventRecord(ctx->ev_copy[j & 1], ctx->copy_stream));
+                           inline_copy ? s : ctx->copy_stream));
+     if (!inline_copy) HIPCHK(hipEventRecord(ctx->ev_copy[j & 1], ctx->copy_stream));
      uploaded = j + 1;
      return BN256_OK;
    };
    for (size_t cj = 0; cj < np_t; cj++, ch++) {
-    const size_t n_ch = std::min(len_t, t.n - cj * len_t);
-    const size_t off_ch = t.off + cj * len_t * stride;
-    const uint8_t* sc_ch = t.sc + cj * len_t * sc_stride * 32;
+    const size_t n_ch = cuts[cj + 1] - cuts[cj];
+    const size_t off_ch = t.off + cuts[cj] * stride;
+    const uint8_t* sc_ch = t.sc + cuts[cj] * sc_stride * 32;
     const unsigned long long entries = (unsigned long long)n_ch * W;
     const u32 K = pick_k(n_ch);
     const size_t T = threads_for(n_ch);
@@ -1089,8 +1110,9 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
     }
 
     if (t.host_sc) {  // this pass's scalars: uploaded on the copy stream (issued during the previous pass)
+      const bool first_of_call = ch == 0 && cj == 0;  // copied on this stream (upload_pass)
       if ((rc = upload_pass(cj))) return rc;
-      HIPCHK(hipStreamWaitEvent(s, ctx->ev_copy[cj & 1], 0));
+      if (!first_of_call) HIPCHK(hipStreamWaitEvent(s, ctx->ev_copy[cj & 1], 0));
     }
     MSM_MARK(0);
     const u32 first_pass = ch == 0 ? 1u : 0u;  // the pass's first kernel clears the counters (heavy_clear), the flags with it here

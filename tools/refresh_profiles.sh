@@ -16,6 +16,15 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wri
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm -- $B > /dev/null 2> $O/pmc_grbm.err
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_sq1 -- $B > /dev/null 2> $O/pmc_sq1.err
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq2 -- $B > /dev/null 2> $O/pmc_sq2.err
+# element-wise rows (h1 loop, generator fold): kernel trace + VALU instruction counts of the two lane kernels
+E="python3 tools/perf_elementwise.py 20"
+rm -rf $O/prof_ew $O/pmc_ew
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ew -o kt -- $E > $O/elementwise.txt 2> $O/elementwise.err
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_ew -- $E > /dev/null 2> $O/pmc_ew.err
+find $O/prof_ew -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_elementwise.csv \;
+# the prover flows on this box (BASELINE.json configs[0], configs[3])
+timeout -k 10 120 python3 tools/bp_bench.py > $O/bp_bench.json 2>/dev/null
+BP_PROFILE=2 timeout -k 10 120 python3 tools/wnla_bench.py > $O/wnla_bench.txt 2>&1
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/prof_kt1 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_depth1.csv \;
 cat $O/bench_2p20.json
