@@ -423,7 +423,7 @@ def worker(args) -> int:
                 entry["matches_oracle_closed_form"] = bool(orc.synth_msm_closed_form(SEED_BASES, SEED_SCALARS, 1 << 24) == resb)
             line["n_2p24" if world == 1 else "strong_2p24"] = entry
         big.free()
-        if world > 1:
+        if world > 1 or use_dist:  # (use_dist at world 1: the one-rank rehearsal, BENCH_FORCE_DIST=1)
             # the same 2^24-point job on rank 0's GPU alone, in this very run (the other ranks' GPUs idle, their
             # processes parked on the rendezvous store): the N = 1 figure the scaling efficiency is taken against
             if rank == 0:
@@ -439,7 +439,7 @@ def worker(args) -> int:
                 res1 = sharding.run_pipelined(ksteps, args.depth, sub1, eng.msm_wait)
                 torch.cuda.synchronize()
                 dt1 = time.perf_counter() - t0
-                e = line["strong_2p24"]
+                e = line["n_2p24" if world == 1 else "strong_2p24"]
                 e["n1_same_run"] = {"ms_per_step": dt1 / ksteps * 1e3, "points_per_s": (1 << 24) * ksteps / dt1,
                                     "setup_seconds_bases": setup1, "same_result": bool(res1 == resb)}
                 e["speedup_vs_n1"] = (dt1 / ksteps) / (dtb / ksteps)

@@ -92,7 +92,7 @@ def test_bench_rank_path_with_a_one_rank_rccl_group(orc):
     that an N > 1 line proves itself with (world size, devices seen by RCCL, per-rank kernel time)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update({"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"})
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-extras", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, timeout=280)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
@@ -108,3 +108,9 @@ def test_bench_rank_path_with_a_one_rank_rccl_group(orc):
     assert len(rk["per_rank"]) == 1 and rk["per_rank"][0]["points"] == n
     assert 0 < rk["k_accumulate_ms_min"] <= rk["k_accumulate_ms_max"] < 5
     assert rk["per_rank"][0]["pci_bus_id"] and rk["per_rank"][0]["device_name"]
+    # the legs only an N > 1 run has: 2^24 points over the ranks, the same job on rank 0's GPU alone in the same run
+    # (the figure `efficiency_vs_n1` is taken against), the one-context-over-all-devices form
+    big = out["n_2p24"]
+    assert bytes.fromhex(big["result_xy"]) == orc.synth_msm_closed_form(0x5EED0001, 0x5EED0002, 1 << 24)
+    assert big["n1_same_run"]["same_result"] is True and 0.7 < big["efficiency_vs_n1"] < 1.4
+    assert out["multi_device_ctx"]["same_result_as_rank_path"] is True
