@@ -34,7 +34,7 @@ for k, ctrs in sorted(acc.items()):
     res[k] = {{"FETCH_SIZE": "FETCH_SIZE_KB", "WRITE_SIZE": "WRITE_SIZE_KB"}.get(c, c): sum(v) / len(v)
               for c, v in sorted(ctrs.items())}
     res[k]["launches"] = max(len(v) for v in ctrs.values())
-res["_note"] = ("rocprofv3 --pmc, one counter block per run (FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE | SQ_*), "
+res["_note"] = os.environ.get("PMC_NOTE") or ("rocprofv3 --pmc, one counter block per run (FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE | SQ_*), "
                 "python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 --depth 1, 2^20 points, default window "
                 "choice (c=20 from 2^20 points on); per-launch means, "
                 "k_accumulate<true> is the timed workload's instantiation (tables proven free of the point at infinity; "
