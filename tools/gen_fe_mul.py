@@ -19,15 +19,41 @@ import os
 
 P = [0x1e089667, 0x02e56362, 0x0d6d6786, 0x1711a241, 0x0dc21ee5, 0x165c30c2, 0x1fe6a9bf, 0x1c695470, 0x008fb501]
 NP = 0x1f17daa9
-SP = 88      # first SGPR used for constants
+SP = 88      # first SGPR used for constants (HOIST = False)
 ACC = "v[0:1]"
+# HOIST: p's limbs and -p^-1 arrive as ten "s" input operands that fe_consts() defines once (one opaque
+# s_mov_b32 each, merged and hoisted out of loops by the compiler) instead of ten s_mov_b32 inside every
+# statement (90 scalar instructions per mixed addition).
+HOIST = os.environ.get("FE_HOIST", "1") != "0"
+
+
+def sk(j, base):
+    return f"%{base + j}" if HOIST else f"s{SP + j}"
+
+
+def prologue(L):
+    if HOIST:
+        return
+    for j in range(9):
+        L.append(f"s_mov_b32 s{SP + j}, {P[j]:#x}")
+    L.append(f"s_mov_b32 s{SP + 9}, {NP:#x}")
+
+
+def consts_fn():
+    L = ["struct fe_sk {", "  u32 k[10];", "};",
+         "// p's limbs 0..8 and -p^-1 mod 2^29 in scalar registers, each defined by one opaque instruction: the",
+         "// compiler cannot rematerialise them as literals, so they stay in ten SGPRs across a kernel's loops.",
+         "__device__ __forceinline__ fe_sk fe_consts() {", "  fe_sk c;"]
+    for j, v in enumerate(P + [NP]):
+        L.append(f'  asm("s_mov_b32 %0, {v:#x}" : "=s"(c.k[{j}]));')
+    L += ["  return c;", "}", "", ""]
+    return "\n".join(L)
 
 
 def emit(square):
     L = []
-    for j in range(9):
-        L.append(f"s_mov_b32 s{SP + j}, {P[j]:#x}")
-    L.append(f"s_mov_b32 s{SP + 9}, {NP:#x}")
+    prologue(L)
+    KB = 27  # first constant operand
     # operand numbering: outputs r0..r8 = %0..%8 ; (square: d0..d8 = %9..%17) ; inputs follow
     r = [f"%{j}" for j in range(9)]
     if square:
@@ -60,14 +86,14 @@ def emit(square):
                 mad(a[i], b[k - i])
         if k <= 8:
             for i in range(0, k):
-                mad(r[i], f"s{SP + k - i}")
-            L.append(f"v_mul_lo_u32 {r[k]}, v0, s{SP + 9}")
+                mad(r[i], sk(k - i, KB))
+            L.append(f"v_mul_lo_u32 {r[k]}, v0, {sk(9, KB)}")
             L.append(f"v_and_b32 {r[k]}, 0x1fffffff, {r[k]}")
-            mad(r[k], f"s{SP}")
+            mad(r[k], sk(0, KB))
             L.append(f"v_ashrrev_i64 {ACC}, 29, {ACC}")
         else:
             for i in range(lo, hi + 1):
-                mad(r[i], f"s{SP + k - i}")
+                mad(r[i], sk(k - i, KB))
             L.append(f"v_and_b32 {r[k - 9]}, 0x1fffffff, v0")
             L.append(f"v_ashrrev_i64 {ACC}, 29, {ACC}")
     L.append(f"v_mov_b32 {r[8]}, v0")
@@ -79,9 +105,8 @@ def emit2():
     r0..r8 = %0..%8 (early clobber), a = %9.., b = %18.., c = %27.., d = %36..  Column bound: 18 products and 9
     quotient terms below 2^58 each plus a carry below 2^35: under 2^63 (fe_mul2add's contract in fe29.cuh)."""
     L = []
-    for j in range(9):
-        L.append(f"s_mov_b32 s{SP + j}, {P[j]:#x}")
-    L.append(f"s_mov_b32 s{SP + 9}, {NP:#x}")
+    prologue(L)
+    KB = 45
     r = [f"%{j}" for j in range(9)]
     a = [f"%{9 + j}" for j in range(9)]
     b = [f"%{18 + j}" for j in range(9)]
@@ -102,14 +127,14 @@ def emit2():
             mad(c[i], d[k - i])
         if k <= 8:
             for i in range(0, k):
-                mad(r[i], f"s{SP + k - i}")
-            L.append(f"v_mul_lo_u32 {r[k]}, v0, s{SP + 9}")
+                mad(r[i], sk(k - i, KB))
+            L.append(f"v_mul_lo_u32 {r[k]}, v0, {sk(9, KB)}")
             L.append(f"v_and_b32 {r[k]}, 0x1fffffff, {r[k]}")
-            mad(r[k], f"s{SP}")
+            mad(r[k], sk(0, KB))
             L.append(f"v_ashrrev_i64 {ACC}, 29, {ACC}")
         else:
             for i in range(lo, hi + 1):
-                mad(r[i], f"s{SP + k - i}")
+                mad(r[i], sk(k - i, KB))
             L.append(f"v_and_b32 {r[k - 9]}, 0x1fffffff, v0")
             L.append(f"v_ashrrev_i64 {ACC}, 29, {ACC}")
     L.append(f"v_mov_b32 {r[8]}, v0")
@@ -123,6 +148,10 @@ def function2(name):
     ins = ", ".join(", ".join(f'"v"({x}.v[{j}])' for j in range(9)) for x in "abcd")
     clob = '"vcc", "v0", "v1", ' + ", ".join(f'"s{SP + j}"' for j in range(10))
     sig = f"__device__ __forceinline__ fe {name}(const fe& a, const fe& b, const fe& c, const fe& d) {{\n  fe r;\n"
+    if HOIST:
+        ins += ", " + ", ".join(f'"s"(K.k[{j}])' for j in range(10))
+        clob = '"vcc", "v0", "v1"'
+        sig += "  const fe_sk K = fe_consts();\n"
     return f"{sig}  asm(\n{body}\n      : {outs}\n      : {ins}\n      : {clob});\n  return r;\n}}\n"
 
 
@@ -138,6 +167,10 @@ def function(name, square):
         ins = ", ".join(f'"v"(a.v[{j}])' for j in range(9)) + ", " + ", ".join(f'"v"(b.v[{j}])' for j in range(9))
         sig = f"__device__ __forceinline__ fe {name}(const fe& a, const fe& b) {{\n  fe r;\n"
     clob = '"vcc", "v0", "v1", ' + ", ".join(f'"s{SP + j}"' for j in range(10))
+    if HOIST:
+        ins += ", " + ", ".join(f'"s"(K.k[{j}])' for j in range(10))
+        clob = '"vcc", "v0", "v1"'
+        sig += "  const fe_sk K = fe_consts();\n"
     tail = "  (void)d0; (void)d1; (void)d2; (void)d3; (void)d4; (void)d5; (void)d6; (void)d7; (void)d8;\n" if square else ""
     return f"{sig}  asm(\n{body}\n      : {outs}\n      : {ins}\n      : {clob});\n{tail}  return r;\n}}\n"
 
@@ -147,6 +180,8 @@ if __name__ == "__main__":
     dst = os.path.join(here, "..", "crypto_amd", "csrc", "fe_mul_gen.inc")
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_fe_mul.py -- do not edit.\n")
+        if HOIST:
+            f.write(consts_fn())
         f.write(function("fe_mul", False))
         f.write("\n")
         f.write(function("fe_sqr", True))
