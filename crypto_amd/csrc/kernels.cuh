@@ -1591,6 +1591,12 @@ __global__ void __launch_bounds__(SMW_BLOCK, 3) k_scalar_mul_win(const aff_mem* 
                                                            u32 broadcast_point, i32* __restrict__ table) {
   __shared__ i32 pre[5][9][SMW_BLOCK];  // prefix products Z_2 ... Z_m for m = 3..7: [m - 3][limb][thread] (Z_2 itself is in the table)
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
+  // Exactly THREE waves per SIMD: the per-lane tables of twelve waves per CU are 201 MB over the chip and stay in
+  // the 256 MB last-level cache; with sixteen (LDS cut to fit eight workgroups) 2^20 points took 11.9 ms instead of
+  // 10.8.  Six workgroups per CU fit the LDS either way, but once the kernel needed <= 128 VGPRs (127 after the
+  // multiplier's constants moved to scalar registers) nothing held a SIMD to three waves and the hardware spread
+  // the twelve unevenly: 12.3 ms.  Naming v135 makes the kernel's register count 136 = three waves per SIMD.
+  asm volatile("v_mov_b32 v135, 0" ::: "v135");
   if (i >= n) return;  // no barrier below: every lane works on its own LDS column and table lines
   fe px, py;
   xyzz res;
