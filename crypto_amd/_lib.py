@@ -42,7 +42,7 @@ EXPORTS = [
     "bn256_add_batch", "bn256_fold", "bn256_bases_download", "bn256_random_bases", "bn256_random_scalars",
     "bn256_g1_sum", "bn256_ctx_set_tuning", "bn256_ctx_set_phase_timing", "bn256_last_timing", "bn256_selftest", "bn256_strerror",
     "bn256_fr_upload", "bn256_fr_random", "bn256_fr_download", "bn256_fr_len", "bn256_fr_device_ptr", "bn256_fr_free",
-    "bn256_fr_fold", "bn256_fr_dot", "bn256_fr_tensor_expand_multi", "bn256_fr_tensor_step_multi", "bn256_ctx_fr_defer_sync", "bn256_fr_fold_multi", "bn256_fr_dot_multi", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait", "bn256_ctx_drain",
+    "bn256_fr_fold", "bn256_fr_dot", "bn256_fr_tensor_expand_multi", "bn256_fr_tensor_step_multi", "bn256_ctx_fr_defer_sync", "bn256_fr_fold_multi", "bn256_fr_dot_multi", "bn256_fr_dot_multi_dev", "bn256_msm_fr", "bn256_msm_fr_multi", "bn256_com_batch", "bn256_glv_split", "bn256_msm_fr_multi_submit", "bn256_msm_multi_submit", "bn256_fold2_submit", "bn256_fold_wait", "bn256_ctx_drain",
 ]
 
 _lib = None
@@ -106,6 +106,8 @@ def load() -> C.CDLL:
     psz, pvp = C.POINTER(sz), C.POINTER(vp)
     lib.bn256_fr_fold_multi.argtypes = [vp, i, pvp, psz, psz, pvp, psz, psz, psz, u8p, u8p, pvp]
     lib.bn256_fr_dot_multi.argtypes = [vp, i, pvp, psz, psz, psz, pvp, psz, psz, psz, C.POINTER(u8p), u8p]
+    if hasattr(lib, "bn256_fr_dot_multi_dev"):  # absent from an older build loaded through BN256MSM_LIB (A/B runs)
+        lib.bn256_fr_dot_multi_dev.argtypes = [vp, i, pvp, psz, psz, psz, pvp, psz, psz, psz, C.POINTER(u8p), pvp]
     if hasattr(lib, "bn256_fr_tensor_step_multi"):  # absent from an older build loaded through BN256MSM_LIB (A/B runs)
         lib.bn256_ctx_fr_defer_sync.argtypes = [vp, i]
         lib.bn256_fr_tensor_step_multi.argtypes = [vp, i, pvp, i, u8p, u8p, pvp]

@@ -205,6 +205,7 @@ struct bn256_ctx {
   bn256_ctx* lane[BN256_ASYNC_LANES];
   struct lane_worker* worker[BN256_ASYNC_LANES];  // the lane's host thread: enqueue, wait and host tail of a submitted call
   struct lane_ticket* pending[BN256_ASYNC_LANES];
+  hipEvent_t lane_ev[BN256_ASYNC_LANES];  // orders a submitted call behind this context's deferred Fr kernels (lane_start)
   // bn256_ctx_create_multi: this context is only the parent of nshard ordinary contexts, one per
   // entry of the device list (it has no stream or workspace of its own)
   int nshard;
@@ -295,6 +296,7 @@ static void ctx_teardown(bn256_ctx* ctx, bool counted) {
   for (int i = 0; i < BN256_ASYNC_LANES; i++) {
     lane_shutdown(ctx, i);  // waits for a submitted call, ends the lane's thread
     bn256_ctx_destroy(ctx->lane[i]);
+    if (ctx->lane_ev[i]) (void)hipEventDestroy(ctx->lane_ev[i]);
   }
   for (int i = 0; i < WS_COUNT; i++)
     if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
@@ -771,6 +773,20 @@ static int lane_start(bn256_ctx* ctx, int l, bool fold, std::function<int(bn256_
   t->fold = fold;
   bn256_ctx* lane = ctx->lane[l];
   lane_worker* w = ctx->worker[l];
+  if (ctx->fr_defer) {
+    // Fr kernels enqueued on this context's stream without a wait (bn256_ctx_fr_defer_sync) may produce what the
+    // submitted call reads: the lane's stream waits for them on the device, the host does not.  The lane is free
+    // (no ticket pending), so nothing else touches its stream now; the job's launches come after this wait.
+    hipError_t e = hipSuccess;
+    if (!ctx->lane_ev[l]) e = hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ctx->lane_ev[l], ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(lane->stream, ctx->lane_ev[l], 0);
+    if (e != hipSuccess) {
+      ctx_note_hip(e, __LINE__);
+      delete t;
+      return BN256_EHIP;
+    }
+  }
   {
     std::lock_guard<std::mutex> lk(w->mu);
     w->busy = true;
@@ -2149,6 +2165,7 @@ struct bn256_frvec {
   size_t n;
   size_t cap;  // bytes of the block behind d (pool)
   int dev;
+  hipEvent_t ready;  // set by bn256_fr_dot_multi_dev under deferred waits: recorded behind the kernels that fill d
 };
 
 static bn256_frvec* frvec_alloc(size_t n, int* rc) {
@@ -2178,6 +2195,7 @@ extern "C" void bn256_fr_free(bn256_ctx* ctx, bn256_frvec* v) {
     (void)hipStreamSynchronize(ctx->stream);
     wait_for_submitted(ctx);
   }
+  if (v->ready) (void)hipEventDestroy(v->ready);
   pool::release(v->d, v->cap, v->dev);
   delete v;
 }
@@ -2222,7 +2240,12 @@ extern "C" int bn256_fr_download(bn256_ctx* ctx, const bn256_frvec* v, size_t of
   PRIMARY_SHARD(ctx);
   if (off > v->n || n > v->n - off) return BN256_ELENGTH;
   HIPCHK(hipSetDevice(ctx->device));
-  if (n) {
+  if (n && v->ready) {
+    // results of bn256_fr_dot_multi_dev: wait for THEIR kernels only, not for whatever the context has enqueued
+    // since (the next rounds' kernels), and copy outside the context's stream for the same reason
+    HIPCHK(hipEventSynchronize(v->ready));
+    HIPCHK(hipMemcpy(scalars_be, v->d + off * 32, n * 32, hipMemcpyDeviceToHost));
+  } else if (n) {
     HIPCHK(hipMemcpyAsync(scalars_be, v->d + off * 32, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
@@ -2383,13 +2406,14 @@ extern "C" int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off,
   return bn256_fr_fold_multi(ctx, 1, &a, &a_off, &n_a, &b, &b_off, &n_b, &stride, s_a_be, s_b_be, out);
 }
 
-extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
-                                  const size_t* a_stride, const size_t* n_a, const bn256_frvec* const* b,
-                                  const size_t* b_off, const size_t* b_stride, const size_t* n_b,
-                                  const uint8_t* const* mu_be, uint8_t* out_be) {
-  if (!ctx || k < 0 || (k && (!a || !a_off || !a_stride || !n_a || !b || !b_off || !b_stride || !n_b || !out_be)))
+// out_be: the k results go to the host (one wait).  out_dev (out_be == nullptr): they stay in HBM as 32-byte
+// big-endian elements at out_dev, nothing is waited for when the context defers its Fr waits.
+static int fr_dot_multi_core(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
+                             const size_t* a_stride, const size_t* n_a, const bn256_frvec* const* b,
+                             const size_t* b_off, const size_t* b_stride, const size_t* n_b,
+                             const uint8_t* const* mu_be, uint8_t* out_be, uint8_t* out_dev) {
+  if (!ctx || k < 0 || (k && (!a || !a_off || !a_stride || !n_a || !b || !b_off || !b_stride || !n_b || (!out_be && !out_dev))))
     return BN256_EINVAL;
-  PRIMARY_SHARD(ctx);
   if (!k) return BN256_OK;
   int rc;
   size_t need = (size_t)k * 32 + 256;
@@ -2404,14 +2428,18 @@ extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* cons
     const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
     need += (size_t)nblocks((n + per - 1) / per, 256) * sizeof(fr) + 256;
   }
-  memset(out_be, 0, (size_t)k * 32);
-  if (!any) return BN256_OK;
   HIPCHK(hipSetDevice(ctx->device));
+  if (out_be) memset(out_be, 0, (size_t)k * 32);
+  if (!any) {
+    if (out_dev) HIPCHK(hipMemsetAsync(out_dev, 0, (size_t)k * 32, ctx->stream));
+    if (out_dev && !ctx->fr_defer) HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BN256_OK;
+  }
   if ((rc = ws_reserve(ctx, WS_TMP, need))) return rc;
   // k results, then every product's partial sums.  The results go straight into the context's mapped pinned
   // buffer when they fit it (they do: 2048 products): no copy behind the summing kernel (see msm_enqueue_srcs)
-  const bool direct = (size_t)k * 32 <= ctx->h_pack_cap;
-  uint8_t* d_out = direct ? (uint8_t*)ctx->d_hpack : (uint8_t*)ctx->ws[WS_TMP];
+  const bool direct = !out_dev && (size_t)k * 32 <= ctx->h_pack_cap;
+  uint8_t* d_out = out_dev ? out_dev : direct ? (uint8_t*)ctx->d_hpack : (uint8_t*)ctx->ws[WS_TMP];
   uint8_t* cur = (uint8_t*)ctx->ws[WS_TMP] + (((size_t)k * 32 + 255) & ~(size_t)255);
   // products in launches of FR_DOT_BATCH; an empty product (nblk = 0) sums to zero
   for (int i0 = 0; i0 < k; i0 += FR_DOT_BATCH) {
@@ -2446,9 +2474,44 @@ extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* cons
     hipLaunchKernelGGL(k_fr_sum, dim3(kb), dim3(256), 0, ctx->stream, batch, d_out + 32 * (size_t)i0);
   }
   HIPCHK(hipGetLastError());
+  if (out_dev) {
+    if (!ctx->fr_defer) HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BN256_OK;
+  }
   if (!direct) HIPCHK(hipMemcpyAsync(out_be, d_out, (size_t)k * 32, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));  // one wait for all products
   if (direct) memcpy(out_be, ctx->h_pack, (size_t)k * 32);
+  return BN256_OK;
+}
+
+extern "C" int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
+                                  const size_t* a_stride, const size_t* n_a, const bn256_frvec* const* b,
+                                  const size_t* b_off, const size_t* b_stride, const size_t* n_b,
+                                  const uint8_t* const* mu_be, uint8_t* out_be) {
+  if (!ctx || (k > 0 && !out_be)) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
+  return fr_dot_multi_core(ctx, k, a, a_off, a_stride, n_a, b, b_off, b_stride, n_b, mu_be, out_be, nullptr);
+}
+
+extern "C" int bn256_fr_dot_multi_dev(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
+                                      const size_t* a_stride, const size_t* n_a, const bn256_frvec* const* b,
+                                      const size_t* b_off, const size_t* b_stride, const size_t* n_b,
+                                      const uint8_t* const* mu_be, bn256_frvec** out) {
+  if (!ctx || !out || k < 1) return BN256_EINVAL;
+  PRIMARY_SHARD(ctx);
+  *out = nullptr;
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  bn256_frvec* v = frvec_alloc((size_t)k, &rc);
+  if (!v) return rc;
+  rc = fr_dot_multi_core(ctx, k, a, a_off, a_stride, n_a, b, b_off, b_stride, n_b, mu_be, nullptr, (uint8_t*)v->d);
+  if (!rc && ctx->fr_defer) {  // bn256_fr_download of this vector then waits for these kernels alone
+    hipError_t e = hipEventCreateWithFlags(&v->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(v->ready, ctx->stream);
+    if (e != hipSuccess) { ctx_note_hip(e, __LINE__); rc = BN256_EHIP; }
+  }
+  if (rc) { bn256_fr_free(ctx, v); return rc; }
+  *out = v;
   return BN256_OK;
 }
 

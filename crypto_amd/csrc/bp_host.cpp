@@ -895,6 +895,27 @@ void devDotMulti(bn256_ctx* ctx, const std::vector<DotArg>& d, Fr* out) {
                          mup.data(), res.data()));
   for (size_t i = 0; i < k; i++) out[i] = fr_from_be(&res[32 * i]);
 }
+// the same with the results left in HBM (bn256_fr_dot_multi_dev): nothing is waited for while the context defers
+DevFr devDotMultiDev(bn256_ctx* ctx, const std::vector<DotArg>& d) {
+  const size_t k = d.size();
+  std::vector<const bn256_frvec*> a(k), b(k);
+  std::vector<size_t> ao(k), as(k), an(k), bo(k), bs(k), bn(k);
+  std::vector<std::vector<uint8_t>> mu(k);
+  std::vector<const uint8_t*> mup(k, nullptr);
+  for (size_t i = 0; i < k; i++) {
+    a[i] = d[i].a->h; ao[i] = d[i].va.off; as[i] = d[i].va.stride; an[i] = d[i].va.len;
+    b[i] = d[i].b->h; bo[i] = d[i].vb.off; bs[i] = d[i].vb.stride; bn[i] = d[i].vb.len;
+    if (d[i].mu) {
+      mu[i].resize(32);
+      fr_to_be(mu[i].data(), *d[i].mu);
+      mup[i] = mu[i].data();
+    }
+  }
+  bn256_frvec* out = nullptr;
+  chk(bn256_fr_dot_multi_dev(ctx, (int)k, a.data(), ao.data(), as.data(), an.data(), b.data(), bo.data(), bs.data(), bn.data(),
+                             mup.data(), &out));
+  return DevFr(ctx, out);
+}
 // three devFoldHalves in one device call (bn256_fr_fold_multi): c', l', n' of a WNLA round
 void devFoldHalves3(bn256_ctx* ctx, const DevFr& v0, const Fr& a0, const Fr& b0, const DevFr& v1, const Fr& a1,
                     const Fr& b1, const DevFr& v2, const Fr& a2, const Fr& b2, DevFr& o0, DevFr& o1, DevFr& o2) {
@@ -1221,7 +1242,8 @@ struct WnlaResult {
 WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr c, Point C, Fr ro, Fr mu, DevFr l,
                 DevFr n, ByteStream* rd) {
   WnlaResult res;
-  HostChain chain;  // updates C beside the rounds (declared after nothing it uses: it only touches C)
+  const FixedBase gTable(g);  // v_x g and v_r g of every round (docs_test.go:1312,1318)
+  HostChain chain;  // finishes X, R and C' beside the rounds (declared after everything its jobs touch: res, gTable, C)
   Prof pf;
   double tp = Prof::now();
   auto lap = [&](int k) {
@@ -1248,41 +1270,60 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
   bool frozen = false;
   int ft = 0;                    // rounds since the freeze
   DevFr wG, wH;                  // the tensor of the fold scalars of those rounds: G' = rho*G0 + y*G1, H' = H0 + y*H1
-  const FixedBase gTable(g);     // v_x g and v_r g of every round (docs_test.go:1312,1318)
   // Frozen rounds run TWO at a time: the protocol is interactive (y comes from the reader, docs_test.go:1294, not
   // from a hash of X and R), so nothing of round k + 1 -- its scalar folds, inner products, expanded vectors --
   // needs X_k or R_k, only the running C' does, and that is read at the very end.  A round's two MSMs take two of
   // the four lanes; while they run the host prepares and submits the next round's on the other two, and only then
   // collects.  Every vector a submitted MSM may still read -- and every vector whose release would wait for the
   // lanes (bn256_fr_free does) -- stays in the round's record until its results are in.
+  // Nor does the host wait inside a frozen round: the five inner products stay in HBM (bn256_fr_dot_multi_dev) --
+  // v_x and v_r enter only X and R, through v_x g and v_r g -- and are read when the round is collected; the
+  // lanes' streams wait on the device for the round's expanded vectors (bn256_ctx_fr_defer_sync).  A small round
+  // was ~0.35 ms, most of it the wait for a chain of tiny kernels; now the host enqueues and moves on, and the
+  // host thread beside it finishes X, R and C' in round order.
   struct PendingRound {
     int tx, tr;
-    Point gx, gr;
-    Fr y;
+    DevFr dots;
+    Fr y, roinv;
     std::vector<DevFr> keep;
   };
   std::deque<PendingRound> pending;
+  // A collected round's vectors are released at the end: bn256_fr_free waits for EVERY lane that holds a call (it
+  // cannot know which one reads the vector), so releasing them here made each collect wait for the round submitted
+  // after it -- the rounds ran one after the other (kernel trace: the lanes' kernels never overlapped).  They are
+  // the small rounds' vectors only (at most kFreeze elements each).
+  std::vector<DevFr> retired;
+  size_t rounds_done = 0;  // res.X belongs to the chain's thread while frozen rounds are being collected
   auto collect = [&]() {
     PendingRound pr = std::move(pending.front());
     pending.pop_front();
-    Point X = pointAdd(pr.gx, devMsmWait(ctx, pr.tx));
-    Point R = pointAdd(pr.gr, devMsmWait(ctx, pr.tr));
-    res.X.push_back(X);
-    res.R.push_back(R);
-    const Fr y = pr.y;
-    chain.push([&C, X, R, y] {  // C is read again only after chain.wait()
+    lap(PF_OTHER);
+    const FrVec d5 = pr.dots.download();  // waits for this context's stream: the round's Fr kernels are long done
+    lap(PF_DOT);
+    const Point mx = devMsmWait(ctx, pr.tx), mr = devMsmWait(ctx, pr.tr);
+    lap(PF_MSM);
+    const Fr y = pr.y, roinv_k = pr.roinv;
+    retired.push_back(std::move(pr.dots));
+    for (DevFr& x : pr.keep) retired.push_back(std::move(x));
+    chain.push([&C, &res, &gTable, d5, mx, mr, y, roinv_k] {  // C, res.X, res.R are read again only after chain.wait()
+      const Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv_k)), add(d5[1], d5[2]));
+      const Fr vr = add(d5[3], d5[4]);
+      const Point X = pointAdd(gTable.mul(vx), mx), R = pointAdd(gTable.mul(vr), mr);
+      res.X.push_back(X);
+      res.R.push_back(R);
       Point C_ = pointAdd(C, scalarMult(X, y));
       C = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
     });
   };
   for (;;) {
     if (per_round) {  // BP_PROFILE=2: the split of every round
-      if (!res.X.empty())
+      if (rounds_done)
         fprintf(stderr, "[wnla] round %zu |l|=%zu: dot=%.3f msm=%.3f host_point=%.3f point_fold=%.3f fr_fold=%.3f other=%.3f\n",
-                res.X.size(), 2 * l.n, pf.t[0] - prev[0], pf.t[1] - prev[1], pf.t[2] - prev[2], pf.t[3] - prev[3],
+                rounds_done, 2 * l.n, pf.t[0] - prev[0], pf.t[1] - prev[1], pf.t[2] - prev[2], pf.t[3] - prev[3],
                 pf.t[4] - prev[4], pf.t[5] - prev[5]);
       for (int i = 0; i < 6; i++) prev[i] = pf.t[i];
     }
+    rounds_done++;
     Fr roinv = fr_inv(ro);
     lap(PF_OTHER);
     if (l.n + n.n < 6) {
@@ -1316,7 +1357,11 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
       // X = v_x g + <H0, l1> + <H1, l0> + rho <G0, n1> + rho^-1 <G1, n0>,  R = v_r g + <H1, l1> + <G1, n1>
       // (docs_test.go:1312-1320) over the frozen H, G: four expanded scalar vectors, one call.  The round's three
       // groups of Fr kernels -- expanded vectors, next round's c, l, n, the five inner products -- are enqueued
-      // back to back and waited for ONCE (the inner products' result is the only thing the host reads).
+      // back to back and not waited for (the inner products are read when the round is collected).
+      // two lanes per round; collected BEFORE this round's kernels are enqueued: reading a round's inner products
+      // waits for this context's stream, which then holds nothing newer than the previous round's kernels
+      while (pending.size() >= BN256_ASYNC_LANES / 2) collect();
+      lap(PF_MSM);
       chk(bn256_ctx_fr_defer_sync(ctx, 1));
       struct DeferOff {
         bn256_ctx* c;
@@ -1326,25 +1371,21 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
                                                    {&n, G.n, &wG, 0, true, ro, roinv},
                                                    {&l, H.n, &wH, 0, false, kFrZero, kFrOne},
                                                    {&n, G.n, &wG, 0, false, kFrZero, kFrOne}}, 0);
-      DevFr c_, l_, n_;
-      devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
       lap(PF_FRFOLD);
-      Fr d5[5];
-      devDotMulti(ctx, {{&n, n0, &n, n1, &mu2}, {&c, c0, &l, l1, nullptr}, {&c, c1, &l, l0, nullptr},
-                        {&n, n1, &n, n1, &mu2}, {&c, c1, &l, l1, nullptr}}, d5);  // waits: e, c_, l_, n_ are complete
-      Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv)), add(d5[1], d5[2]));
-      Fr vr = add(d5[3], d5[4]);
-      lap(PF_DOT);
-      while (pending.size() >= BN256_ASYNC_LANES / 2) collect();  // two lanes per round
-      lap(PF_MSM);
+      // the commitments first: their lanes wait (on the device) for what this context has enqueued so far, which
+      // should be the expanded vectors and not also the inner products
       PendingRound pr;
       pr.y = y;
+      pr.roinv = roinv;
       pr.tx = devMsmFusedSubmit(ctx, {{&H, whole(H.n), &e[0], whole(e[0].n), nullptr}, {&G, whole(G.n), &e[1], whole(e[1].n), nullptr}});
       pr.tr = devMsmFusedSubmit(ctx, {{&H, whole(H.n), &e[2], whole(e[2].n), nullptr}, {&G, whole(G.n), &e[3], whole(e[3].n), nullptr}});
       lap(PF_MSM);
-      pr.gx = gTable.mul(vx);
-      pr.gr = gTable.mul(vr);
-      lap(PF_HOSTPT);
+      DevFr c_, l_, n_;
+      devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
+      lap(PF_FRFOLD);
+      pr.dots = devDotMultiDev(ctx, {{&n, n0, &n, n1, &mu2}, {&c, c0, &l, l1, nullptr}, {&c, c1, &l, l0, nullptr},
+                                     {&n, n1, &n, n1, &mu2}, {&c, c1, &l, l1, nullptr}});
+      lap(PF_DOT);
       // this round's vectors retire with its record (their release would wait for the lanes)
       for (DevFr& x : e) pr.keep.push_back(std::move(x));
       pr.keep.push_back(std::move(c));

@@ -337,6 +337,22 @@ class Engine:
                                               (C.c_char_p * m)(*mus), out))
         return [int.from_bytes(out.raw[32 * j:32 * j + 32], "big") for j in range(k)]
 
+    def fr_dot_multi_dev(self, items: Sequence[tuple]) -> FrVec:
+        """The same k >= 1 inner products with the results left in HBM as a new vector (bn256_fr_dot_multi_dev);
+        under fr_defer_sync(True) nothing is waited for until the vector is downloaded."""
+        k = len(items)
+        col = lambda j: (C.c_size_t * k)(*[it[j] for it in items])  # noqa: E731
+        mus = [(int(it[8]).to_bytes(32, "big") if len(it) > 8 and it[8] is not None else None) for it in items]
+        out = C.c_void_p()
+        self._chk(self.lib.bn256_fr_dot_multi_dev(self.ctx, k, (C.c_void_p * k)(*[it[0].h for it in items]), col(1), col(2),
+                                                  col(3), (C.c_void_p * k)(*[it[4].h for it in items]), col(5), col(6),
+                                                  col(7), (C.c_char_p * k)(*mus), C.byref(out)))
+        return FrVec(self, out)
+
+    def fr_defer_sync(self, on: bool) -> None:
+        """bn256_ctx_fr_defer_sync: Fr calls without a host-visible result stop waiting for the stream."""
+        self._chk(self.lib.bn256_ctx_fr_defer_sync(self.ctx, 1 if on else 0))
+
     def fr_fold_multi(self, items: Sequence[tuple]) -> list[FrVec]:
         """items: (a, a_off, n_a, b, b_off, n_b, s_a, s_b, stride) -- k folds, one device call."""
         k = len(items)

@@ -260,6 +260,15 @@ int bn256_fr_fold_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, cons
 int bn256_fr_dot_multi(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off, const size_t* a_stride,
                        const size_t* n_a, const bn256_frvec* const* b, const size_t* b_off, const size_t* b_stride,
                        const size_t* n_b, const uint8_t* const* mu_be, uint8_t* out_be);
+/* The same k inner products with the results left in HBM: *out is a new vector of k elements.  Nothing crosses
+ * PCIe and, while bn256_ctx_fr_defer_sync is on, nothing is waited for: v_x and v_r of a WNLA round
+ * (go/bppp/docs_test.go:1297-1311) enter only X and R through v_x g and v_r g (:1312,1318), which the next
+ * round does not need (its y comes from the reader, :1294), so a prover reads them with bn256_fr_download when
+ * it collects the round's commitments instead of waiting for them inside the round (bn256_fr_download of *out
+ * then waits for these k products alone, not for what the context has enqueued since).  k >= 1. */
+int bn256_fr_dot_multi_dev(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
+                           const size_t* a_stride, const size_t* n_a, const bn256_frvec* const* b, const size_t* b_off,
+                           const size_t* b_stride, const size_t* n_b, const uint8_t* const* mu_be, bn256_frvec** out);
 
 /* Scalar vectors for MSMs over generators that were NOT folded.  After t folding rounds G' = lo G_a (+) hi G_b
  * (WNLA: G'[i] = rho G[2i] + y G[2i+1], go/bppp/docs_test.go:1325-1326; inner-product argument:
@@ -290,10 +299,12 @@ int bn256_fr_tensor_expand_multi(bn256_ctx* ctx, int k, const bn256_frvec* const
 /* Batching of small Fr calls.  A proof's small rounds are a handful of tiny kernels each (three vector folds, four
  * expanded vectors, five inner products: go/bppp/docs_test.go:1297-1334), and a wait per call (~25 us) was
  * most of such a round.  While on, the calls that return no host-visible value -- bn256_fr_fold(_multi),
- * bn256_fr_tensor_expand_multi -- return as soon as their kernels are enqueued; the results are defined for
- * every later call on this context at once (same stream), and for everyone else -- the lanes of the submit calls
- * included -- after the next call that does wait (bn256_fr_dot(_multi), bn256_fr_download, bn256_ctx_drain, any
- * blocking MSM).  Off by default. */
+ * bn256_fr_tensor_expand_multi, bn256_fr_dot_multi_dev -- return as soon as their kernels are enqueued; the
+ * results are defined for every later call on this context at once (same stream) and for every call SUBMITTED to
+ * a lane while the setting is on (bn256_msm_submit and its relatives, bn256_fold2_submit: the lane's stream waits
+ * on the device for what this context had enqueued when the call was submitted); for everyone else after the
+ * next call that does wait (bn256_fr_dot(_multi), bn256_fr_download, bn256_ctx_drain, any blocking MSM).  Off by
+ * default. */
 int bn256_ctx_fr_defer_sync(bn256_ctx* ctx, int on);
 
 /* bn256_msm over views: sum_i v[v_off + i*v_stride] * b[off + i*stride], scalars never leave

@@ -339,3 +339,50 @@ def test_tensor_expand_half_folds_of_the_inner_product_argument(eng):
     assert eng.msm(cur, a[n1:], off=0) == eng.msm_fr(g, 0, 1, n0, outs[2])        # lower generators, upper scalars
     for o in outs + owned + ws + [g, hv]:
         o.free()
+
+
+def test_dot_results_left_on_the_device_and_lanes_ordered_behind_deferred_kernels(eng):
+    """bn256_fr_dot_multi_dev: the WNLA round's five inner products (go/bppp/docs_test.go:1297-1311) left in HBM --
+    the same values as bn256_fr_dot_multi, with and without bn256_ctx_fr_defer_sync; and the ordering the deferred
+    mode promises: an MSM SUBMITTED to a lane right behind un-waited Fr kernels (the expanded scalar vectors of a
+    round over frozen generators) reads their finished output -- many rounds in a row, each result against the
+    blocking call made after a wait."""
+    rng = random.Random(99)
+    nl, nn = 1001, 500
+    l, n, c = _vals(rng, nl), _vals(rng, nn), _vals(rng, nl)
+    mu2 = rng.randrange(1, N)
+    hl, hn, hc = eng.fr_upload(l), eng.fr_upload(n), eng.fr_upload(c)
+    ev = lambda m: (0, 2, (m + 1) // 2)              # noqa: E731
+    od = lambda m: (1 if m > 1 else 0, 2, m // 2)   # noqa: E731
+    items = [(hn, *ev(nn), hn, *od(nn), mu2), (hc, *ev(nl), hl, *od(nl)), (hc, *od(nl), hl, *ev(nl)),
+             (hn, *od(nn), hn, *od(nn), mu2), (hc, *od(nl), hl, *od(nl), None), (hl, 0, 1, 0, hl, 0, 1, 0)]
+    want = eng.fr_dot_multi(items)
+    d = eng.fr_dot_multi_dev(items)
+    assert len(d) == len(items) and d.download() == want
+    d.free()
+    with pytest.raises(crypto_amd.BN256Error):
+        eng.fr_dot_multi_dev([])
+    n0 = 4096
+    g = eng.random_bases(0x7E51, n0)
+    a = eng.fr_upload(_vals(rng, n0 >> 3))
+    w = None
+    for s in range(3):
+        w = eng.fr_tensor_step([(w, rng.randrange(1, N), rng.randrange(1, N))])[0]
+    eng.fr_defer_sync(True)
+    try:
+        keep, tickets, dots = [], [], []
+        for r in range(12):
+            se, so = rng.randrange(N), rng.randrange(N)
+            e = eng.fr_tensor_expand([(a, n0, w, 0, r & 1, se, so)])[0]        # enqueued, not waited for
+            tickets.append(eng.msm_fr_multi_submit([(g, 0, 1, n0, e, 0, 1)]))  # the lane waits on the device
+            dots.append(eng.fr_dot_multi_dev(items))                           # behind it on the context's stream
+            keep.append(e)
+            if len(tickets) == crypto_amd.ASYNC_LANES:
+                got = [eng.msm_wait(t) for t in tickets]
+                assert [x.download() for x in dots] == [want] * len(dots)
+                assert got == [eng.msm_fr(g, 0, 1, n0, x) for x in keep[-len(got):]]
+                tickets, dots = [], []
+    finally:
+        eng.fr_defer_sync(False)
+    for o in keep + [g, a, w, hl, hn, hc]:
+        o.free()
