@@ -1073,6 +1073,12 @@ InnerProductProof innerArgProofFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoi
     Fr cl = vectorMul(alo, bhi), cr = vectorMul(ahi, blo);
     DevFr da(ctx, a), db(ctx, b);
     // L = <G[n1:], a[:n1]> + <H[:n1], b[n1:]> + cl*U ; R = <G[:n1], a[n1:]> + <H[n1:], b[:n1]> + cr*U ; P = <G, a> + <H, b> + <a,b>*U
+    // (the expanded vectors are not waited for by the host: the three lanes wait for them on the device)
+    chk(bn256_ctx_fr_defer_sync(ctx, 1));
+    struct DeferOff {
+      bn256_ctx* c;
+      ~DeferOff() { (void)bn256_ctx_fr_defer_sync(c, 0); }
+    } defer_off{ctx};
     std::vector<DevFr> e = devTensorExpand(ctx, {{&da, Nf, &wG, sel, true, kFrZero, kFrOne}, {&db, Nf, &wH, sel, true, kFrOne, kFrZero},
                                                  {&da, Nf, &wG, sel, true, kFrOne, kFrZero}, {&db, Nf, &wH, sel, true, kFrZero, kFrOne},
                                                  {&da, Nf, &wG, sel, false, kFrOne, kFrOne}, {&db, Nf, &wH, sel, false, kFrOne, kFrOne}}, 1);
