@@ -2304,17 +2304,31 @@ extern "C" int bn256_fr_fold_multi(bn256_ctx* ctx, int k, const bn256_frvec* con
       out[i] = nullptr;
     }
   };
-  for (int i = 0; i < k; i++) {
-    const size_t n = std::max(n_a[i], n_b[i]);
-    if (!(out[i] = frvec_alloc(n, &rc))) {
-      undo();
-      return rc;
+  for (int i0 = 0; i0 < k; i0 += FR_BATCH) {  // up to FR_BATCH folds per launch
+    const int kb = std::min(k - i0, (int)FR_BATCH);
+    fr_fold_batch batch;
+    memset(&batch, 0, sizeof batch);
+    u32 max_blk = 0;
+    for (int j = 0; j < kb; j++) {
+      const int i = i0 + j;
+      const size_t n = std::max(n_a[i], n_b[i]);
+      if (!(out[i] = frvec_alloc(n, &rc))) {
+        undo();
+        return rc;
+      }
+      fr_fold_desc& D = batch.d[j];
+      D.a = (const uint8_t*)(a[i]->d + a_off[i] * 32);
+      D.b = (const uint8_t*)(b[i]->d + b_off[i] * 32);
+      D.out = out[i]->d;
+      D.n_a = (u32)n_a[i];
+      D.n_b = (u32)n_b[i];
+      D.stride = (u32)stride[i];
+      D.n = (u32)n;
+      D.s_a = fr_arg_canon(fr_arg_from_be(s_a_be + 32 * i));
+      D.s_b = fr_arg_canon(fr_arg_from_be(s_b_be + 32 * i));
+      max_blk = std::max(max_blk, nblocks(n, 256));
     }
-    if (n)
-      hipLaunchKernelGGL(k_fr_fold, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream,
-                         (const uint8_t*)(a[i]->d + a_off[i] * 32), (u32)n_a[i], (const uint8_t*)(b[i]->d + b_off[i] * 32),
-                         (u32)n_b[i], (u32)stride[i], fr_arg_canon(fr_arg_from_be(s_a_be + 32 * i)),
-                         fr_arg_canon(fr_arg_from_be(s_b_be + 32 * i)), out[i]->d, (u32)n);
+    if (max_blk) hipLaunchKernelGGL(k_fr_fold, dim3(max_blk, kb), dim3(256), 0, ctx->stream, batch);
   }
   hipError_t e = ctx->fr_defer ? hipGetLastError() : hipStreamSynchronize(ctx->stream);  // one wait for all k folds
   if (e != hipSuccess) {
@@ -2337,18 +2351,30 @@ extern "C" int bn256_fr_tensor_step_multi(bn256_ctx* ctx, int k, const bn256_frv
     if (w[i] && (!is_pow2(w[i]->n) || w[i]->n >= (1u << 30))) return BN256_EINVAL;
   }
   HIPCHK(hipSetDevice(ctx->device));
-  for (int i = 0; i < k; i++) {
-    const size_t len = w[i] ? w[i]->n : 1;
-    if (!(out[i] = frvec_alloc(2 * len, &rc))) {
-      for (int j = 0; j < i; j++) {
-        bn256_fr_free(ctx, out[j]);
-        out[j] = nullptr;
+  for (int i0 = 0; i0 < k; i0 += FR_BATCH) {
+    const int kb = std::min(k - i0, (int)FR_BATCH);
+    fr_step_batch batch;
+    memset(&batch, 0, sizeof batch);
+    u32 max_blk = 0;
+    for (int j = 0; j < kb; j++) {
+      const int i = i0 + j;
+      const size_t len = w[i] ? w[i]->n : 1;
+      if (!(out[i] = frvec_alloc(2 * len, &rc))) {
+        for (int q = 0; q < i; q++) {
+          bn256_fr_free(ctx, out[q]);
+          out[q] = nullptr;
+        }
+        return rc;
       }
-      return rc;
+      fr_step_desc& D = batch.d[j];
+      D.w = (const uint8_t*)(w[i] ? w[i]->d : nullptr);
+      D.out = out[i]->d;
+      D.len = (u32)len;
+      D.lo = fr_arg_canon(fr_arg_from_be(lo_be + 32 * i));
+      D.hi = fr_arg_canon(fr_arg_from_be(hi_be + 32 * i));
+      max_blk = std::max(max_blk, nblocks(2 * len, 256));
     }
-    hipLaunchKernelGGL(k_fr_tensor_step, dim3(nblocks(2 * len, 256)), dim3(256), 0, ctx->stream,
-                       (const uint8_t*)(w[i] ? w[i]->d : nullptr), (u32)len, (u32)layout,
-                       fr_arg_canon(fr_arg_from_be(lo_be + 32 * i)), fr_arg_canon(fr_arg_from_be(hi_be + 32 * i)), out[i]->d);
+    hipLaunchKernelGGL(k_fr_tensor_step, dim3(max_blk, kb), dim3(256), 0, ctx->stream, batch, (u32)layout);
   }
   HIPCHK(hipGetLastError());
   return BN256_OK;  // no wait: the only readers are later calls on this context, on the same stream
@@ -2377,18 +2403,33 @@ extern "C" int bn256_fr_tensor_expand_multi(bn256_ctx* ctx, int k, const bn256_f
       out[i] = nullptr;
     }
   };
-  for (int i = 0; i < k; i++) {
-    if (!(out[i] = frvec_alloc(n_out[i], &rc))) {
-      undo();
-      return rc;
+  for (int i0 = 0; i0 < k; i0 += FR_BATCH) {
+    const int kb = std::min(k - i0, (int)FR_BATCH);
+    fr_expand_batch batch;
+    memset(&batch, 0, sizeof batch);
+    u32 max_blk = 0;
+    for (int j = 0; j < kb; j++) {
+      const int i = i0 + j;
+      if (!(out[i] = frvec_alloc(n_out[i], &rc))) {
+        undo();
+        return rc;
+      }
+      u32 t = 0;
+      while (w[i] && ((size_t)1 << t) < w[i]->n) t++;
+      fr_expand_desc& D = batch.d[j];
+      D.v = (const uint8_t*)v[i]->d;
+      D.w = (const uint8_t*)(w[i] ? w[i]->d : nullptr);
+      D.out = out[i]->d;
+      D.n_v = (u32)v[i]->n;
+      D.n_out = (u32)n_out[i];
+      D.t = t;
+      D.sel = (u32)sel[i];
+      D.swap = (u32)(swap[i] != 0);
+      D.s_clear = fr_arg_canon(fr_arg_from_be(s_clear_be + 32 * i));
+      D.s_set = fr_arg_canon(fr_arg_from_be(s_set_be + 32 * i));
+      max_blk = std::max(max_blk, nblocks(n_out[i], 256));
     }
-    if (!n_out[i]) continue;
-    u32 t = 0;
-    while (w[i] && ((size_t)1 << t) < w[i]->n) t++;
-    hipLaunchKernelGGL(k_fr_tensor_expand, dim3(nblocks(n_out[i], 256)), dim3(256), 0, ctx->stream, (const uint8_t*)v[i]->d,
-                       (u32)v[i]->n, (u32)n_out[i], t, (u32)layout, (u32)sel[i], (u32)(swap[i] != 0),
-                       (const uint8_t*)(w[i] ? w[i]->d : nullptr), fr_arg_canon(fr_arg_from_be(s_clear_be + 32 * i)),
-                       fr_arg_canon(fr_arg_from_be(s_set_be + 32 * i)), out[i]->d);
+    if (max_blk) hipLaunchKernelGGL(k_fr_tensor_expand, dim3(max_blk, kb), dim3(256), 0, ctx->stream, batch, (u32)layout);
   }
   hipError_t e = ctx->fr_defer ? hipGetLastError() : hipStreamSynchronize(ctx->stream);  // one wait for all k vectors
   if (e != hipSuccess) {
@@ -2406,6 +2447,11 @@ extern "C" int bn256_fr_fold(bn256_ctx* ctx, const bn256_frvec* a, size_t a_off,
   return bn256_fr_fold_multi(ctx, 1, &a, &a_off, &n_a, &b, &b_off, &n_b, &stride, s_a_be, s_b_be, out);
 }
 
+// elements per thread: eight or more for throughput (a thread pays ~1.5 log2(start) products for its first weight);
+// two for the small vectors of a proof's late rounds, where the product is one latency chain
+static u32 fr_dot_per(size_t n) {
+  return n <= 4096 ? 2u : (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+}
 // out_be: the k results go to the host (one wait).  out_dev (out_be == nullptr): they stay in HBM as 32-byte
 // big-endian elements at out_dev, nothing is waited for when the context defers its Fr waits.
 static int fr_dot_multi_core(bn256_ctx* ctx, int k, const bn256_frvec* const* a, const size_t* a_off,
@@ -2425,7 +2471,7 @@ static int fr_dot_multi_core(bn256_ctx* ctx, int k, const bn256_frvec* const* a,
     const size_t n = std::min(n_a[i], n_b[i]);  // the padded tail multiplies by zero
     if (!n) continue;
     any = true;
-    const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+    const u32 per = fr_dot_per(n);
     need += (size_t)nblocks((n + per - 1) / per, 256) * sizeof(fr) + 256;
   }
   HIPCHK(hipSetDevice(ctx->device));
@@ -2451,7 +2497,7 @@ static int fr_dot_multi_core(bn256_ctx* ctx, int k, const bn256_frvec* const* a,
       const int i = i0 + j;
       const size_t n = std::min(n_a[i], n_b[i]);
       if (!n) continue;
-      const u32 per = (u32)std::max<size_t>(8, (n + 256 * 1024 - 1) / (256 * 1024));
+      const u32 per = fr_dot_per(n);
       const u32 nthreads = (u32)((n + per - 1) / per);
       fr_dot_desc& D = batch.d[j];
       D.nblk = nblocks(nthreads, 256);

@@ -136,16 +136,28 @@ __device__ __forceinline__ fr fr_from_arg(const fr_arg& a) {
 // out[i] = s_a * a[a_off + i*stride] + s_b * b[b_off + i*stride]; an index past n_a / n_b reads 0
 // (BP++'s pad-tolerant vectorAdd, go/bppp/util.go:245-260; IPA halves go/bp/main.go:357-358;
 // WNLA l' = l0 + y l1, n' = rho^-1 n0 + y n1, go/bppp/docs_test.go:1318-1319).
-__global__ void __launch_bounds__(256) k_fr_fold(const uint8_t* __restrict__ a, u32 n_a, const uint8_t* __restrict__ b,
-                                                 u32 n_b, u32 stride, fr_arg s_a, fr_arg s_b,
-                                                 uint8_t* __restrict__ out, u32 n) {
+// Up to FR_BATCH folds per launch (blockIdx.y picks the fold): a WNLA round has three (c', l', n'), and in a
+// proof's small rounds a launch costs the host more than the arithmetic costs the device.
+#define FR_BATCH 8
+struct fr_fold_desc {
+  const uint8_t* a;
+  const uint8_t* b;
+  uint8_t* out;
+  u32 n_a, n_b, stride, n;
+  fr_arg s_a, s_b;
+};
+struct fr_fold_batch {
+  fr_fold_desc d[FR_BATCH];
+};
+__global__ void __launch_bounds__(256) k_fr_fold(fr_fold_batch batch) {
+  const fr_fold_desc& D = batch.d[blockIdx.y];
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fr sa = fr_to_mont(fr_from_arg(s_a)), sb = fr_to_mont(fr_from_arg(s_b));
+  if (i >= D.n) return;
+  fr sa = fr_to_mont(fr_from_arg(D.s_a)), sb = fr_to_mont(fr_from_arg(D.s_b));
   fr r = fr_zero();
-  if (i < n_a) r = fr_mont(fr_load_be(a + (size_t)i * stride * 32), sa);
-  if (i < n_b) r = fr_add(r, fr_mont(fr_load_be(b + (size_t)i * stride * 32), sb));
-  fr_store_be(out + (size_t)i * 32, r);
+  if (i < D.n_a) r = fr_mont(fr_load_be(D.a + (size_t)i * D.stride * 32), sa);
+  if (i < D.n_b) r = fr_add(r, fr_mont(fr_load_be(D.b + (size_t)i * D.stride * 32), sb));
+  fr_store_be(D.out + (size_t)i * 32, r);
 }
 
 // partials[block] = sum_i a_i * b_i * (weighted ? mu^(i+1) : 1) over the block's share of
@@ -232,39 +244,59 @@ __global__ void __launch_bounds__(256) k_fr_sum(fr_dot_batch batch, uint8_t* __r
 //   layout 1, half folds (inner-product argument, go/bp/main.go:355-356: G'[i] = lo G[i] + hi G[i + n/2]):
 //             m = I + n_t j, a new round is the new LOW bit of j.
 // k_fr_tensor_step: w' = the weights after one more round (w = [1] before the first).
-__global__ void __launch_bounds__(256) k_fr_tensor_step(const uint8_t* __restrict__ w, u32 len, u32 layout, fr_arg lo,
-                                                        fr_arg hi, uint8_t* __restrict__ out) {
+struct fr_step_desc {
+  const uint8_t* w;
+  uint8_t* out;
+  u32 len;
+  fr_arg lo, hi;
+};
+struct fr_step_batch {
+  fr_step_desc d[FR_BATCH];
+};
+__global__ void __launch_bounds__(256) k_fr_tensor_step(fr_step_batch batch, u32 layout) {
+  const fr_step_desc& D = batch.d[blockIdx.y];
   u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 len = D.len;
   if (m >= 2 * len) return;
   const u32 b = layout ? (m & 1u) : (m >= len ? 1u : 0u), j = layout ? (m >> 1) : (b ? m - len : m);
-  const fr f = fr_to_mont(fr_from_arg(b ? hi : lo));
+  const fr f = fr_to_mont(fr_from_arg(b ? D.hi : D.lo));
   fr x;
-  if (w) {
-    x = fr_load_be(w + (size_t)j * 32);
+  if (D.w) {
+    x = fr_load_be(D.w + (size_t)j * 32);
   } else {
     x = fr_zero();
     x.w[0] = 1;
   }
-  fr_store_be(out + (size_t)m * 32, fr_mont(x, f));
+  fr_store_be(D.out + (size_t)m * 32, fr_mont(x, f));
 }
 // out[m] = w[j] * s(I) * v[I ^ (swap << sel)], with (I, j) = (m >> t, m mod 2^t) in layout 0 and
 // (m mod n_t, m / n_t) in layout 1 (n_t = n_out >> t, a power of two there); s(I) = s_set when bit `sel` of I is
 // set, s_clear otherwise; a source index past n_v reads 0 (the BP++ zero padding).  swap = 1 pairs each half
-// with the OTHER half's scalars (<H0, l1> + <H1, l0>; <G[n1:], a[:n1]>).
-__global__ void __launch_bounds__(256) k_fr_tensor_expand(const uint8_t* __restrict__ v, u32 n_v, u32 n_out, u32 t,
-                                                          u32 layout, u32 sel, u32 swap, const uint8_t* __restrict__ w,
-                                                          fr_arg s_clear, fr_arg s_set, uint8_t* __restrict__ out) {
+// with the OTHER half's scalars (<H0, l1> + <H1, l0>; <G[n1:], a[:n1]>).  Up to FR_BATCH vectors per launch.
+struct fr_expand_desc {
+  const uint8_t* v;
+  const uint8_t* w;
+  uint8_t* out;
+  u32 n_v, n_out, t, sel, swap;
+  fr_arg s_clear, s_set;
+};
+struct fr_expand_batch {
+  fr_expand_desc d[FR_BATCH];
+};
+__global__ void __launch_bounds__(256) k_fr_tensor_expand(fr_expand_batch batch, u32 layout) {
+  const fr_expand_desc& D = batch.d[blockIdx.y];
   u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n_out) return;
-  const u32 nI = n_out >> t;
+  if (m >= D.n_out) return;
+  const u32 t = D.t, sel = D.sel;
+  const u32 nI = D.n_out >> t;
   const u32 I = layout ? (m & (nI - 1u)) : (m >> t), j = layout ? (m / nI) : (m & ((1u << t) - 1u));
-  const u32 src = I ^ (swap << sel);
+  const u32 src = I ^ (D.swap << sel);
   fr r = fr_zero();
-  if (src < n_v) {
-    r = fr_mont(fr_load_be(v + (size_t)src * 32), fr_to_mont(fr_from_arg(((I >> sel) & 1u) ? s_set : s_clear)));
-    if (w) r = fr_mont(r, fr_to_mont(fr_load_be(w + (size_t)j * 32)));
+  if (src < D.n_v) {
+    r = fr_mont(fr_load_be(D.v + (size_t)src * 32), fr_to_mont(fr_from_arg(((I >> sel) & 1u) ? D.s_set : D.s_clear)));
+    if (D.w) r = fr_mont(r, fr_to_mont(fr_load_be(D.w + (size_t)j * 32)));
   }
-  fr_store_be(out + (size_t)m * 32, r);
+  fr_store_be(D.out + (size_t)m * 32, r);
 }
 
 // Gathers one (points view, scalars view) segment into contiguous arrays so that several

@@ -11,7 +11,7 @@ from typing import Iterable, Sequence
 from . import _lib
 
 PRECOMPUTE = 1
-ASYNC_LANES = 4  # BN256_ASYNC_LANES (include/bn256msm.h): calls in flight per context
+ASYNC_LANES = 8  # BN256_ASYNC_LANES (include/bn256msm.h): calls in flight per context
 INF = bytes(64)
 
 

@@ -136,9 +136,12 @@ int bn256_msm_dev_noalloc(bn256_ctx* ctx, const bn256_bases* b, size_t off, size
  * errors are reported by submit; errors of the call itself (BN256_ENOMEM, BN256_EHIP) by wait.  The
  * scalars must stay untouched, and the bases handle alive, until the matching wait; a submit while
  * every lane holds a call returns BN256_EBUSY; tickets are lane numbers, valid for one wait.  One caller
- * thread per context, as everywhere in this library.  Four lanes: a WNLA round has its two commitments
- * and its two generator folds (go/bppp/docs_test.go:1312-1326) in flight together. */
-#define BN256_ASYNC_LANES 4
+ * thread per context, as everywhere in this library.  Eight lanes (each is created at its first use): a WNLA
+ * round has its two commitments and its two generator folds (go/bppp/docs_test.go:1312-1326) in flight
+ * together, and a proof's small rounds -- latency chains of ~0.5 ms per commitment -- run four rounds deep
+ * (the protocol's challenges come from the reader, not from X and R: docs_test.go:1294); with four lanes the
+ * WNLA at |l| = 2^20 took 17.2-17.9 ms, with eight 16.6-17.1.  bench.py keeps four calls in flight. */
+#define BN256_ASYNC_LANES 8
 int bn256_msm_submit(bn256_ctx* ctx, const bn256_bases* b, size_t off, size_t n, const void* d_scalars_be,
                      int* ticket);
 int bn256_msm_wait(bn256_ctx* ctx, int ticket, uint8_t out_xy_be[64]);

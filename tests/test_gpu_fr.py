@@ -345,7 +345,7 @@ def test_dot_results_left_on_the_device_and_lanes_ordered_behind_deferred_kernel
     """bn256_fr_dot_multi_dev: the WNLA round's five inner products (go/bppp/docs_test.go:1297-1311) left in HBM --
     the same values as bn256_fr_dot_multi, with and without bn256_ctx_fr_defer_sync; and the ordering the deferred
     mode promises: an MSM SUBMITTED to a lane right behind un-waited Fr kernels (the expanded scalar vectors of a
-    round over frozen generators) reads their finished output -- many rounds in a row, each result against the
+    round over frozen generators) reads their finished output -- three times as many rounds in a row as there are lanes, each result against the
     blocking call made after a wait."""
     rng = random.Random(99)
     nl, nn = 1001, 500
@@ -371,7 +371,7 @@ def test_dot_results_left_on_the_device_and_lanes_ordered_behind_deferred_kernel
     eng.fr_defer_sync(True)
     try:
         keep, tickets, dots = [], [], []
-        for r in range(12):
+        for r in range(3 * crypto_amd.ASYNC_LANES):
             se, so = rng.randrange(N), rng.randrange(N)
             e = eng.fr_tensor_expand([(a, n0, w, 0, r & 1, se, so)])[0]        # enqueued, not waited for
             tickets.append(eng.msm_fr_multi_submit([(g, 0, 1, n0, e, 0, 1)]))  # the lane waits on the device
@@ -382,6 +382,7 @@ def test_dot_results_left_on_the_device_and_lanes_ordered_behind_deferred_kernel
                 assert [x.download() for x in dots] == [want] * len(dots)
                 assert got == [eng.msm_fr(g, 0, 1, n0, x) for x in keep[-len(got):]]
                 tickets, dots = [], []
+        assert not tickets
     finally:
         eng.fr_defer_sync(False)
     for o in keep + [g, a, w, hl, hn, hc]:
