@@ -25,6 +25,9 @@ find $O/prof_ew -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_elementwis
 # the prover flows on this box (BASELINE.json configs[0], configs[3])
 timeout -k 10 120 python3 tools/bp_bench.py > $O/bp_bench.json 2>/dev/null
 BP_PROFILE=2 timeout -k 10 120 python3 tools/wnla_bench.py > $O/wnla_bench.txt 2>&1
+rm -rf $O/wnla_kt
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/wnla_kt -o kt -- python3 tools/wnla_bench.py 20 > $O/wnla_kt.txt 2> $O/wnla_kt.err
+find $O/wnla_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_wnla.csv \;
 find $O/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/prof_kt1 -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_depth1.csv \;
 cat $O/bench_2p20.json
