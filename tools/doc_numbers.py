@@ -64,9 +64,24 @@ if "n_2p24" in bench:
 if "multi_device_ctx" in bench and "median_ms" in bench["multi_device_ctx"]:
     m = bench["multi_device_ctx"]
     L.append(f"| `multi_device_ctx`: `bn256_ctx_create_multi`, devices {m['devices']}, 2²⁴ points | {m['median_ms']:.2f} ms = {m['points_per_s'] / 1e6:.0f} Mpts/s ({m.get('note', 'one shard per device')}); same bytes as the rank path: {m.get('same_result_as_rank_path')} |")
+if "no_table_2p20" in bench:
+    b = bench["no_table_2p20"]
+    L.append(f"| `no_table_2p20`: one blocking table-less call (the reference's loop has no precomputation) | {b['median_ms']:.3f} ms = {b['points_per_s'] / 1e6:.0f} Mpts/s, whole-MSM fraction {b['whole_msm_frac']:.3f}; same bytes as the fixed-base call: {b.get('same_result_as_fixed_base')} |")
+if "h1_2p20" in bench and "fold_2p19" in bench:
+    h, f = bench["h1_2p20"], bench["fold_2p19"]
+    L.append(f"| `h1_2p20` (a9: 2²⁰ per-point scalar multiplications, scalars uploaded inside the call) / `fold_2p19` (a7: 2¹⁹ fold outputs) | {h['median_ms']:.2f} ms = {h['points_per_s'] / 1e6:.0f} M points/s, issue fraction {h['imad_issue_frac']:.2f} / {f['median_ms']:.2f} ms = {f['outputs_per_s'] / 1e6:.0f} M outputs/s, issue fraction {f['imad_issue_frac']:.2f}; sampled outputs match the closed form: {h.get('sampled_outputs_match_closed_form')}, {f.get('sampled_outputs_match_closed_form')} |")
+if "bp_n64" in bench:
+    b = bench["bp_n64"]
+    L.append(f"| `bp_n64` (configs[0]: go/bp range proof, N = 64) | prove {b['prove_median_ms']:.2f} ms, verify {b['verify_median_ms']:.2f} ms (medians of {b['runs']}); verify accepts: {b['verify_accepts']}, tampered proof rejected: {b['tampered_rejected']} |")
+if "bppp_2p20" in bench:
+    b = bench["bppp_2p20"]
+    w = b.get("wnla_2p20", {})
+    L.append(f"| `bppp_2p20` (configs[3]: BP++ commitments of {b['terms_per_commitment']} terms; WNLA at \|l\| = 2²⁰) | {b['blocking']['ms_per_commitment']:.2f} ms per commitment blocking ({b['blocking']['points_per_s'] / 1e6:.0f} Mpts/s), {b['on_lanes']['ms_per_commitment']:.2f} ms on lanes; closed form: {b.get('matches_oracle_closed_form')}; WNLA {w.get('median_ms', float('nan')):.2f} ms, {w.get('rounds')} rounds, final check passes: {w.get('final_check_passes')} |")
 if "cpu_baseline" in bench:
     c = bench["cpu_baseline"]
-    L.append(f"| `cpu_baseline` (C restatement of the reference loop, {c['cores']} thread) | {c['value']:.0f} points/s |")
+    ac = c.get("all_cores")
+    extra = f"; all {ac['cores']} host cores (not the reference, which is single-goroutine): {ac['value']:.0f} points/s" if ac else ""
+    L.append(f"| `cpu_baseline` (C restatement of the reference loop, {c['cores']} thread; host: {c.get('host_cpu', {}).get('model_name', '?')}, {c.get('host_cpu', {}).get('os_cpu_count', '?')} CPUs) | {c['value']:.0f} points/s{extra} |")
 L.append("")
 L.append("| kernel (rocprofv3 kernel trace, `--depth 1`: one call on the chip) | launches per call | average µs |")
 L.append("|---|---|---|")
