@@ -7,6 +7,7 @@
 // This is product code; it shares nothing with oracle/.
 #include <cstdint>
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -372,20 +373,29 @@ struct DevPoints {  // a []*bn256.G1 resident in HBM
   bn256_ctx* ctx = nullptr;
   bn256_bases* h = nullptr;
   size_t n = 0;
+  bool owned = true;  // false: someone else's handle (the caller's public generators), never freed here
   DevPoints() {}
   DevPoints(bn256_ctx* c, bn256_bases* b) : ctx(c), h(b), n(bn256_bases_len(b)) {}
+  // A protocol never writes into the generators it is given -- a fold makes a NEW handle and the old one is
+  // dropped -- so the first level can work on the caller's handle as it stands (a clone was a download and an
+  // upload, two waits, per proof).
+  static DevPoints borrow(bn256_ctx* c, const bn256_bases* b) {
+    DevPoints d(c, const_cast<bn256_bases*>(b));
+    d.owned = false;
+    return d;
+  }
   DevPoints(const DevPoints&) = delete;
   DevPoints& operator=(const DevPoints&) = delete;
-  DevPoints(DevPoints&& o) noexcept : ctx(o.ctx), h(o.h), n(o.n) { o.h = nullptr; }
+  DevPoints(DevPoints&& o) noexcept : ctx(o.ctx), h(o.h), n(o.n), owned(o.owned) { o.h = nullptr; }
   DevPoints& operator=(DevPoints&& o) noexcept {
     if (this != &o) {
-      if (h) bn256_bases_free(ctx, h);
-      ctx = o.ctx; h = o.h; n = o.n; o.h = nullptr;
+      if (h && owned) bn256_bases_free(ctx, h);
+      ctx = o.ctx; h = o.h; n = o.n; owned = o.owned; o.h = nullptr;
     }
     return *this;
   }
   ~DevPoints() {
-    if (h) bn256_bases_free(ctx, h);
+    if (h && owned) bn256_bases_free(ctx, h);
   }
   Point at(size_t i) const {
     Point p;
@@ -463,6 +473,7 @@ struct InnerProductProof {  // go/bp/main.go:253-260
 // s-vector MSM).  Same group elements, same transcript.  BP_IPA_FREEZE=<n> moves the threshold (0: always fold).
 struct DevFr;
 struct IpaFrozen;
+static Point fixedMult(const Point& g, const Fr& k);  // k*g over a cached table of g (below): U is multiplied 3 log N times
 static size_t ipaFreeze() {
   static const size_t v = getenv("BP_IPA_FREEZE") ? (size_t)strtoull(getenv("BP_IPA_FREEZE"), nullptr, 10) : 4096;
   return v;
@@ -488,7 +499,7 @@ InnerProductProof innerArgProof(bn256_ctx* ctx, int N, DevPoints G, DevPoints H,
     int tl = msmSegmentsSubmit(ctx, {{&G, n1, alo}, {&H, 0, bhi}});
     int tr = msmSegmentsSubmit(ctx, {{&G, 0, ahi}, {&H, n1, blo}});
     int tp = msmSegmentsSubmit(ctx, {{&G, 0, a}, {&H, 0, b}});
-    Point ul = scalarMult(U, cl), ur = scalarMult(U, cr), up = scalarMult(U, vectorMul(a, b));
+    Point ul = fixedMult(U, cl), ur = fixedMult(U, cr), up = fixedMult(U, vectorMul(a, b));
     Point L = pointAdd(msmWait(ctx, tl), ul);
     Point R = pointAdd(msmWait(ctx, tr), ur);
     Point P = pointAdd(msmWait(ctx, tp), up);
@@ -553,6 +564,76 @@ std::string innerArgVerify(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, cons
   Point p = pointAdd(com(G.at(0), H.at(0), proof.A, proof.B), scalarMult(U, mul(proof.A, proof.B)));
   if (!pointEq(P, p)) return "failed to verify inner argument proof";
   return "";
+}
+
+// k * g for ONE point g and many k (wnla's v_x g and v_r g, two per round, docs_test.go:1312,1318): signed-free
+// 4-bit windows over the two GLV halves, table d * 16^w * g for w < 33, d < 16 (495 additions to build, once),
+// then 66 additions per product instead of scalarMult's 130 doublings + ~97 additions.
+class FixedBase {
+  std::vector<hostg1::Pt> T;  // [w][d - 1]
+  bool inf = false;
+
+ public:
+  explicit FixedBase(const Point& g) {
+    hostg1::Pt b = pt_load(g);
+    inf = hostg1::is_inf(b);
+    if (inf) return;
+    T.resize(33 * 15);
+    for (int w = 0; w < 33; w++) {
+      T[15 * w] = b;
+      for (int d = 2; d <= 15; d++) T[15 * w + d - 1] = hostg1::padd(T[15 * w + d - 2], b);
+      b = hostg1::padd(T[15 * w + 14], b);  // 16 * b
+    }
+  }
+  Point mul(const Fr& k) const {
+    if (inf) return pt_from(hostg1::infinity());
+    static const hostg1::Fp beta = [] {
+      const uint64_t w[4] = {0xb9ff3815a6c2a92eULL, 0x877db38fb92fa161ULL, 0xcb5601bf83f4fcf8ULL, 0};
+      return hostg1::from_raw(w);
+    }();
+    uint8_t kb[32], k1b[32], k2b[32];
+    int n1 = 0, n2 = 0;
+    fr_to_be(kb, k);
+    if (int rc = bn256_glv_split(kb, k1b, &n1, k2b, &n2)) throw std::runtime_error(bn256_strerror(rc));
+    const hostg1::Fp zero = {{0, 0, 0, 0}};
+    hostg1::Pt acc = hostg1::infinity();
+    for (int h = 0; h < 2; h++) {
+      const uint8_t* kk = h ? k2b : k1b;  // big-endian magnitude below 2^130
+      const bool neg = h ? n2 != 0 : n1 != 0;
+      for (int w = 0; w < 33; w++) {
+        const int byte = 31 - w / 2;
+        const unsigned d = (w & 1) ? (kk[byte] >> 4) : (kk[byte] & 15);
+        if (!d) continue;
+        hostg1::Pt t = T[15 * w + d - 1];
+        if (h) t.x = hostg1::mul(t.x, beta);
+        if (neg) t.y = hostg1::sub(zero, t.y);
+        acc = hostg1::padd(acc, t);
+      }
+    }
+    return pt_from(acc);
+  }
+};
+
+// The commitment bases g, h and U of a BulletProofPublic are public parameters that every proof of a set-up
+// multiplies again (com() x 3, h*alpha, h*rho, the verifier's g*delta, h*(-nu), U*tx: go/bp/main.go:92-123,
+// 209-245): their FixedBase tables are kept, keyed by the 64 point bytes, for the process's lifetime (a handful
+// of entries; the oldest goes when there are more than 16).
+static std::shared_ptr<const FixedBase> fixedBaseFor(const Point& g) {
+  static std::mutex mu;
+  static std::deque<std::pair<std::array<uint8_t, 64>, std::shared_ptr<const FixedBase>>> cache;
+  std::array<uint8_t, 64> key;
+  memcpy(key.data(), g.b, 64);
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& e : cache)
+    if (e.first == key) return e.second;
+  auto t = std::make_shared<const FixedBase>(g);
+  cache.emplace_back(key, t);
+  if (cache.size() > 16) cache.pop_front();
+  return t;
+}
+static Point fixedMult(const Point& g, const Fr& k) { return fixedBaseFor(g)->mul(k); }
+static Point fixedCom(const Point& g, const Point& h, const Fr& a, const Fr& b) {  // com(), go/bp/util.go:92-94
+  return pointAdd(fixedMult(g, a), fixedMult(h, b));
 }
 
 struct BulletProofPublic {  // go/bp/main.go:17-24
@@ -633,8 +714,8 @@ BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const
   FrVec sl = rd.values(N), sr = rd.values(N);
   Fr ro = rd.values(1)[0];
   int ts = msmSegmentsSubmit(ctx, {{&p.G, 0, sl}, {&p.H, 0, sr}});
-  Point ha = scalarMult(p.h, alpha), hs = scalarMult(p.h, ro);
-  Point V = com(p.g, p.h, v, prv);
+  Point ha = fixedMult(p.h, alpha), hs = fixedMult(p.h, ro);
+  Point V = fixedCom(p.g, p.h, v, prv);
   Point A = pointAdd(msmWait(ctx, ta), ha);
   Point S = pointAdd(msmWait(ctx, ts), hs);
   BulletProof proof;
@@ -651,8 +732,8 @@ BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const
                                       hadamardMul(yn, vectorAdd(ar, vectorMulOnScalar(onen, z))))));
   Fr t2 = vectorMul(hadamardMul(yn, sr), sl);
   Fr tau1 = rd.values(1)[0], tau2 = rd.values(1)[0];
-  proof.T1Com = com(p.g, p.h, t1, tau1);
-  proof.T2Com = com(p.g, p.h, t2, tau2);
+  proof.T1Com = fixedCom(p.g, p.h, t1, tau1);
+  proof.T2Com = fixedCom(p.g, p.h, t2, tau2);
   Fr x = hashFS({y, z}, {proof.T1Com, proof.T2Com});
   Fr x2 = mul(x, x);
   FrVec l = vectorAdd(vectorSub(al, vectorMulOnScalar(onen, z)), vectorMulOnScalar(sl, x));
@@ -667,7 +748,7 @@ BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const
   std::vector<uint8_t> yb = scalarBytes(yinvn);
   bn256_bases* h1 = nullptr;
   chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &h1));
-  InnerProductProof ip = innerArgProof(ctx, N, cloneRange(ctx, p.G), DevPoints(ctx, h1), p.U, l, r);
+  InnerProductProof ip = innerArgProof(ctx, N, DevPoints::borrow(ctx, p.G.h), DevPoints(ctx, h1), p.U, l, r);
   proof.A = ip.A;
   proof.B = ip.B;
   proof.L = ip.L;
@@ -691,9 +772,9 @@ std::string verify(bn256_ctx* ctx, const BulletProofPublic& p, const BulletProof
   chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &h1raw));
   DevPoints h1(ctx, h1raw);
   Fr deltayz = sub(mul(sub(z, z2), vectorMul(onen, yn)), mul(z3, vectorMul(onen, twon)));
-  Point c1 = com(p.g, p.h, proof.Tx, proof.TauX);
+  Point c1 = fixedCom(p.g, p.h, proof.Tx, proof.TauX);
   Point c2 = scalarMult(proof.V, z2);
-  c2 = pointAdd(c2, scalarMult(p.g, deltayz));
+  c2 = pointAdd(c2, fixedMult(p.g, deltayz));
   c2 = pointAdd(c2, scalarMult(proof.T1Com, x));
   c2 = pointAdd(c2, scalarMult(proof.T2Com, x2));
   if (!pointEq(c1, c2)) return "failed: tx ?= t0 + t1*x +t2*x^2";
@@ -701,14 +782,14 @@ std::string verify(bn256_ctx* ctx, const BulletProofPublic& p, const BulletProof
   P = pointAdd(P, vectorPointScalarMul(ctx, p.G, 0, (size_t)N, vectorMulOnScalar(onen, sub(kFrZero, z))));
   P = pointAdd(P, vectorPointScalarMul(ctx, h1, 0, (size_t)N,
                                        vectorAdd(vectorMulOnScalar(yn, z), vectorMulOnScalar(twon, z2))));
-  P = pointAdd(P, scalarMult(p.h, sub(kFrZero, proof.Nu)));
-  P = pointAdd(P, scalarMult(p.U, proof.Tx));
+  P = pointAdd(P, fixedMult(p.h, sub(kFrZero, proof.Nu)));
+  P = pointAdd(P, fixedMult(p.U, proof.Tx));
   InnerProductProof ip;
   ip.L = proof.L;
   ip.R = proof.R;
   ip.A = proof.A;
   ip.B = proof.B;
-  return innerArgVerify(ctx, N, cloneRange(ctx, p.G), std::move(h1), p.U, P, ip);
+  return innerArgVerify(ctx, N, DevPoints::borrow(ctx, p.G.h), std::move(h1), p.U, P, ip);
 }
 
 // ------------------------------------------------------------------ wire format
@@ -1085,7 +1166,7 @@ InnerProductProof innerArgProofFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoi
     int tl = devMsmFusedSubmit(ctx, {{&G, whole(Nf), &e[0], whole(Nf), nullptr}, {&H, whole(Nf), &e[1], whole(Nf), nullptr}});
     int tr = devMsmFusedSubmit(ctx, {{&G, whole(Nf), &e[2], whole(Nf), nullptr}, {&H, whole(Nf), &e[3], whole(Nf), nullptr}});
     int tp = devMsmFusedSubmit(ctx, {{&G, whole(Nf), &e[4], whole(Nf), nullptr}, {&H, whole(Nf), &e[5], whole(Nf), nullptr}});
-    Point ul = scalarMult(U, cl), ur = scalarMult(U, cr), up = scalarMult(U, vectorMul(a, b));
+    Point ul = fixedMult(U, cl), ur = fixedMult(U, cr), up = fixedMult(U, vectorMul(a, b));
     Point L = pointAdd(devMsmWait(ctx, tl), ul);
     Point R = pointAdd(devMsmWait(ctx, tr), ur);
     Point P = pointAdd(devMsmWait(ctx, tp), up);
@@ -1127,54 +1208,6 @@ std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H
   if (!pointEq(P, p)) return "failed to verify inner argument proof";
   return "";
 }
-
-// k * g for ONE point g and many k (wnla's v_x g and v_r g, two per round, docs_test.go:1312,1318): signed-free
-// 4-bit windows over the two GLV halves, table d * 16^w * g for w < 33, d < 16 (495 additions to build, once),
-// then 66 additions per product instead of scalarMult's 130 doublings + ~97 additions.
-class FixedBase {
-  std::vector<hostg1::Pt> T;  // [w][d - 1]
-  bool inf = false;
-
- public:
-  explicit FixedBase(const Point& g) {
-    hostg1::Pt b = pt_load(g);
-    inf = hostg1::is_inf(b);
-    if (inf) return;
-    T.resize(33 * 15);
-    for (int w = 0; w < 33; w++) {
-      T[15 * w] = b;
-      for (int d = 2; d <= 15; d++) T[15 * w + d - 1] = hostg1::padd(T[15 * w + d - 2], b);
-      b = hostg1::padd(T[15 * w + 14], b);  // 16 * b
-    }
-  }
-  Point mul(const Fr& k) const {
-    if (inf) return pt_from(hostg1::infinity());
-    static const hostg1::Fp beta = [] {
-      const uint64_t w[4] = {0xb9ff3815a6c2a92eULL, 0x877db38fb92fa161ULL, 0xcb5601bf83f4fcf8ULL, 0};
-      return hostg1::from_raw(w);
-    }();
-    uint8_t kb[32], k1b[32], k2b[32];
-    int n1 = 0, n2 = 0;
-    fr_to_be(kb, k);
-    if (int rc = bn256_glv_split(kb, k1b, &n1, k2b, &n2)) throw std::runtime_error(bn256_strerror(rc));
-    const hostg1::Fp zero = {{0, 0, 0, 0}};
-    hostg1::Pt acc = hostg1::infinity();
-    for (int h = 0; h < 2; h++) {
-      const uint8_t* kk = h ? k2b : k1b;  // big-endian magnitude below 2^130
-      const bool neg = h ? n2 != 0 : n1 != 0;
-      for (int w = 0; w < 33; w++) {
-        const int byte = 31 - w / 2;
-        const unsigned d = (w & 1) ? (kk[byte] >> 4) : (kk[byte] & 15);
-        if (!d) continue;
-        hostg1::Pt t = T[15 * w + d - 1];
-        if (h) t.x = hostg1::mul(t.x, beta);
-        if (neg) t.y = hostg1::sub(zero, t.y);
-        acc = hostg1::padd(acc, t);
-      }
-    }
-    return pt_from(acc);
-  }
-};
 
 // One host thread that runs small jobs in order, beside the caller: wnla's running commitment
 // C' = C + y X + (y^2 - 1) R (two host scalar multiplications per round, ~85 us) is needed only by the
@@ -1848,12 +1881,6 @@ extern "C" int bp_verify_det(bn256_ctx* ctx, int n, uint64_t seed, const uint8_t
 
 // ---- product entry points: the caller's generators (resident handles), blinding from the OS CSPRNG
 namespace {
-// a []*bn256.G1 the caller owns, seen as DevPoints for the duration of a call
-struct Borrowed {
-  DevPoints d;
-  Borrowed(bn256_ctx* c, const bn256_bases* b) : d(c, const_cast<bn256_bases*>(b)) {}
-  ~Borrowed() { d.h = nullptr; }
-};
 bool pointOk(const uint8_t b[64]) {
   hostg1::Pt t;
   return hostg1::unmarshal(t, b) == 0;
@@ -1864,9 +1891,8 @@ BulletProofPublic publicFrom(bn256_ctx* ctx, int n, const bn256_bases* G, const 
   if (!pointOk(U) || !pointOk(g) || !pointOk(h)) throw std::runtime_error("bn256: malformed point");
   BulletProofPublic p;
   p.N = n;
-  Borrowed bg(ctx, G), bh(ctx, H);
-  p.G = cloneRange(ctx, bg.d);
-  p.H = cloneRange(ctx, bh.d);
+  p.G = DevPoints::borrow(ctx, G);
+  p.H = DevPoints::borrow(ctx, H);
   memcpy(p.U.b, U, 64);
   memcpy(p.g.b, g, 64);
   memcpy(p.h.b, h, 64);
@@ -1954,7 +1980,7 @@ extern "C" int bp_inner_product_roundtrip(bn256_ctx* ctx, int n, uint64_t seed, 
       b[i] = fr_from_be(b_be + 32 * i);
     }
     Point P = pointAdd(msmSegments(ctx, {{&G, 0, a}, {&H, 0, b}}), scalarMult(U, vectorMul(a, b)));
-    InnerProductProof ip = innerArgProof(ctx, n, cloneRange(ctx, G), cloneRange(ctx, H), U, a, b);
+    InnerProductProof ip = innerArgProof(ctx, n, DevPoints::borrow(ctx, G.h), DevPoints::borrow(ctx, H.h), U, a, b);
     if (tamper) ip.A = add(ip.A, kFrOne);
     std::string e = innerArgVerify(ctx, n, std::move(G), std::move(H), U, P, ip);
     g_err = e;
