@@ -16,6 +16,7 @@
 #include <deque>
 #include <exception>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -704,6 +705,19 @@ DevPoints cloneRange(bn256_ctx* ctx, const DevPoints& g) {  // a second handle o
 }
 
 // (*BulletProofPublic).Prove, go/bp/main.go:81-178.  Randomness order: alpha, sl, sr, ro, tau1, tau2.
+// a handle a helper thread is producing: collected by take(), or freed if the caller leaves early
+struct PendingBases {
+  std::future<bn256_bases*> f;
+  bn256_ctx* c;
+  bn256_bases* take() { return f.get(); }
+  ~PendingBases() {
+    if (!f.valid()) return;
+    try {
+      if (bn256_bases* r = f.get()) bn256_bases_free(c, r);
+    } catch (...) {
+    }
+  }
+};
 BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const Fr& prv, ByteStream& rd) {
   const int N = p.N;
   FrVec onen = ones(N);
@@ -723,6 +737,16 @@ BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const
   proof.ACom = A;
   proof.SCom = S;
   Fr y = hashFS({fr_from_u64((uint64_t)N)}, {A, S, V});
+  // h1[i] = H[i] * yinvn[i]   (main.go:156-159), batched on device.  It needs only y: the call (one latency chain of
+  // ~0.5 ms at N = 64) runs on a helper thread while this one does the host algebra down to nu, which makes no
+  // library call (the context is used by one thread at a time).
+  FrVec yinvn = invntharr(y, N);
+  std::vector<uint8_t> yb = scalarBytes(yinvn);
+  PendingBases h1f{std::async(std::launch::async, [ctx, &p, &yb, N]() {
+                     bn256_bases* r = nullptr;
+                     chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &r));
+                     return r;
+                   }), ctx};
   Fr z = hashFS({y}, {A, S});
   FrVec yn = ntharr(y, N);
   Fr z2 = mul(z, z);
@@ -743,11 +767,7 @@ BulletProof prove(bn256_ctx* ctx, const BulletProofPublic& p, const Fr& v, const
   proof.Tx = vectorMul(l, r);
   proof.TauX = add(mul(tau2, x2), add(mul(tau1, x), mul(z2, prv)));
   proof.Nu = add(alpha, mul(ro, x));
-  // h1[i] = H[i] * yinvn[i]   (main.go:156-159), batched on device
-  FrVec yinvn = invntharr(y, N);
-  std::vector<uint8_t> yb = scalarBytes(yinvn);
-  bn256_bases* h1 = nullptr;
-  chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &h1));
+  bn256_bases* h1 = h1f.take();
   InnerProductProof ip = innerArgProof(ctx, N, DevPoints::borrow(ctx, p.G.h), DevPoints(ctx, h1), p.U, l, r);
   proof.A = ip.A;
   proof.B = ip.B;
@@ -768,9 +788,12 @@ std::string verify(bn256_ctx* ctx, const BulletProofPublic& p, const BulletProof
   Fr x2 = mul(x, x);
   FrVec yinvn = invntharr(y, N);
   std::vector<uint8_t> yb = scalarBytes(yinvn);
-  bn256_bases* h1raw = nullptr;
-  chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &h1raw));
-  DevPoints h1(ctx, h1raw);
+  // h1 on a helper thread under the host's tx check (as in prove: no library call until it is collected)
+  PendingBases h1f{std::async(std::launch::async, [ctx, &p, &yb, N]() {
+                     bn256_bases* r = nullptr;
+                     chk(bn256_scalar_mul_batch(ctx, p.H.h, 0, (size_t)N, yb.data(), 0, &r));
+                     return r;
+                   }), ctx};
   Fr deltayz = sub(mul(sub(z, z2), vectorMul(onen, yn)), mul(z3, vectorMul(onen, twon)));
   Point c1 = fixedCom(p.g, p.h, proof.Tx, proof.TauX);
   Point c2 = scalarMult(proof.V, z2);
@@ -779,6 +802,7 @@ std::string verify(bn256_ctx* ctx, const BulletProofPublic& p, const BulletProof
   c2 = pointAdd(c2, scalarMult(proof.T2Com, x2));
   if (!pointEq(c1, c2)) return "failed: tx ?= t0 + t1*x +t2*x^2";
   Point P = pointAdd(proof.ACom, scalarMult(proof.SCom, x));
+  DevPoints h1(ctx, h1f.take());
   P = pointAdd(P, vectorPointScalarMul(ctx, p.G, 0, (size_t)N, vectorMulOnScalar(onen, sub(kFrZero, z))));
   P = pointAdd(P, vectorPointScalarMul(ctx, h1, 0, (size_t)N,
                                        vectorAdd(vectorMulOnScalar(yn, z), vectorMulOnScalar(twon, z2))));
