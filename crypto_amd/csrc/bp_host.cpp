@@ -449,8 +449,9 @@ Point msmWait(bn256_ctx* ctx, int ticket) {
   chk(bn256_msm_wait(ctx, ticket, out.b));
   return out;
 }
-// vectorPointScalarMul, go/bp/util.go:165-175
-Point vectorPointScalarMul(bn256_ctx* ctx, const DevPoints& g, size_t off, size_t len, const FrVec& a) {
+// vectorPointScalarMul, go/bp/util.go:165-175 (every call site of the mirror now sums several of them in one
+// msmSegments; the single form stays for a caller that wants the reference's helper by name)
+[[maybe_unused]] Point vectorPointScalarMul(bn256_ctx* ctx, const DevPoints& g, size_t off, size_t len, const FrVec& a) {
   if (len != a.size()) throw std::runtime_error("invalid length for scalar mul");
   return msmSegments(ctx, {{&g, off, a}});
 }
@@ -803,9 +804,9 @@ std::string verify(bn256_ctx* ctx, const BulletProofPublic& p, const BulletProof
   if (!pointEq(c1, c2)) return "failed: tx ?= t0 + t1*x +t2*x^2";
   Point P = pointAdd(proof.ACom, scalarMult(proof.SCom, x));
   DevPoints h1(ctx, h1f.take());
-  P = pointAdd(P, vectorPointScalarMul(ctx, p.G, 0, (size_t)N, vectorMulOnScalar(onen, sub(kFrZero, z))));
-  P = pointAdd(P, vectorPointScalarMul(ctx, h1, 0, (size_t)N,
-                                       vectorAdd(vectorMulOnScalar(yn, z), vectorMulOnScalar(twon, z2))));
+  // P += <G, -z 1^n> + <h1, z y^n + z^2 2^n>   (main.go:225-226): the two vectorPointScalarMul as ONE device MSM
+  P = pointAdd(P, msmSegments(ctx, {{&p.G, 0, vectorMulOnScalar(onen, sub(kFrZero, z))},
+                                    {&h1, 0, vectorAdd(vectorMulOnScalar(yn, z), vectorMulOnScalar(twon, z2))}}));
   P = pointAdd(P, fixedMult(p.h, sub(kFrZero, proof.Nu)));
   P = pointAdd(P, fixedMult(p.U, proof.Tx));
   InnerProductProof ip;
@@ -1145,6 +1146,66 @@ std::vector<DevFr> devTensorExpand(bn256_ctx* ctx, const std::vector<ExpandArg>&
   for (size_t i = 0; i < k; i++) r.emplace_back(ctx, out[i]);
   return r;
 }
+// One host thread that runs small jobs in order, beside the caller: wnla's running commitment
+// C' = C + y X + (y^2 - 1) R (two host scalar multiplications per round, ~85 us) is needed only by the
+// final check, so it does not have to sit between a round's last wait and the next round's submits.
+class HostChain {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> q;
+  std::exception_ptr err;
+  bool busy = false, quit = false;
+  void run() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return quit || !q.empty(); });
+      if (q.empty()) return;
+      std::function<void()> job = std::move(q.front());
+      q.pop_front();
+      busy = true;
+      lk.unlock();
+      try {
+        job();
+      } catch (...) {
+        lk.lock();
+        if (!err) err = std::current_exception();
+        lk.unlock();
+      }
+      lk.lock();
+      busy = false;
+      cv.notify_all();
+    }
+  }
+
+ public:
+  HostChain() : th([this] { run(); }) {}
+  ~HostChain() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+  void push(std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      q.push_back(std::move(job));
+    }
+    cv.notify_all();
+  }
+  void wait() {  // every job pushed so far has run; rethrows the first exception of one
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return q.empty() && !busy; });
+    if (err) {
+      std::exception_ptr e = err;
+      err = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+};
+
 // ---- the inner-product argument over frozen generators (declared above innerArgProof)
 static int ilog2(size_t n) {
   int r = 0;
@@ -1214,12 +1275,19 @@ std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H
   const size_t Nf = (size_t)N;
   DevFr wG, wH;
   std::vector<DevFr> keep;
+  HostChain helper;
   while (N != 1) {
     if (deep >= proof.L.size() || deep >= proof.R.size()) return "failed to verify inner argument proof";
     Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, proof.L[deep], proof.R[deep]});
     Fr xinv = fr_inv(x), x2 = mul(x, x), x2inv = fr_inv(x2);
     ipaStep(ctx, wG, wH, x, xinv, keep);  // enqueued only: the device works beside the host's P update
-    P = pointAdd(pointAdd(scalarMult(proof.L[deep], x2), P), scalarMult(proof.R[deep], x2inv));
+    // x^2 L and x^-2 R (main.go:305-307) are the verifier's critical path -- 2 x ~85 us a level, and the next
+    // challenge hashes the P they give -- so the second one runs on the helper thread
+    Point rx;
+    helper.push([&rx, &proof, deep, x2inv] { rx = scalarMult(proof.R[deep], x2inv); });
+    const Point lx = scalarMult(proof.L[deep], x2);
+    helper.wait();
+    P = pointAdd(pointAdd(lx, P), rx);
     N /= 2;
     deep++;
   }
@@ -1232,66 +1300,6 @@ std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H
   if (!pointEq(P, p)) return "failed to verify inner argument proof";
   return "";
 }
-
-// One host thread that runs small jobs in order, beside the caller: wnla's running commitment
-// C' = C + y X + (y^2 - 1) R (two host scalar multiplications per round, ~85 us) is needed only by the
-// final check, so it does not have to sit between a round's last wait and the next round's submits.
-class HostChain {
-  std::thread th;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::deque<std::function<void()>> q;
-  std::exception_ptr err;
-  bool busy = false, quit = false;
-  void run() {
-    std::unique_lock<std::mutex> lk(mu);
-    for (;;) {
-      cv.wait(lk, [&] { return quit || !q.empty(); });
-      if (q.empty()) return;
-      std::function<void()> job = std::move(q.front());
-      q.pop_front();
-      busy = true;
-      lk.unlock();
-      try {
-        job();
-      } catch (...) {
-        lk.lock();
-        if (!err) err = std::current_exception();
-        lk.unlock();
-      }
-      lk.lock();
-      busy = false;
-      cv.notify_all();
-    }
-  }
-
- public:
-  HostChain() : th([this] { run(); }) {}
-  ~HostChain() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      quit = true;
-    }
-    cv.notify_all();
-    th.join();
-  }
-  void push(std::function<void()> job) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      q.push_back(std::move(job));
-    }
-    cv.notify_all();
-  }
-  void wait() {  // every job pushed so far has run; rethrows the first exception of one
-    std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return q.empty() && !busy; });
-    if (err) {
-      std::exception_ptr e = err;
-      err = nullptr;
-      std::rethrow_exception(e);
-    }
-  }
-};
 
 struct WnlaResult {
   std::vector<Point> X, R;
