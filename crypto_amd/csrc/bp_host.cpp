@@ -1227,9 +1227,72 @@ static void ipaStep(bn256_ctx* ctx, DevFr& wG, DevFr& wH, const Fr& x, const Fr&
   wG = DevFr(ctx, out[0]);
   wH = DevFr(ctx, out[1]);
 }
+// The same expansion on the host, for frozen sets so small that the device's way costs more in calls than in
+// arithmetic (two uploads with a wait each, the expansion and tensor-step launches, six vector handles to make
+// and to release -- every release waits for the stream): at N = 64 a level's six vectors are 4 N = 256 products,
+// ~6 us on one core.  k_fr_tensor_expand / k_fr_tensor_step, layout 1, restated: out[m] = W[m / n_t] * v[I ^ (swap
+// << sel)] where bit `sel` of I = m mod n_t equals `half`, 0 elsewhere; W' = interleave(lo W, hi W).
+static size_t ipaHostExpand() {  // read at every call: the tests switch between the two ways inside one process
+  const char* e = getenv("BP_IPA_HOST_EXPAND");
+  return e ? (size_t)strtoull(e, nullptr, 10) : 512;
+}
+static FrVec hostExpand(const FrVec& v, const FrVec& W, size_t n_out, size_t n_t, int sel, bool swap, int half) {
+  FrVec out(n_out, kFrZero);  // half: 0 / 1 = only where the bit is clear / set, 2 = everywhere
+  for (size_t m = 0; m < n_out; m++) {
+    const size_t I = m & (n_t - 1), j = m / n_t, bit = (I >> sel) & 1u;
+    if (half != 2 && (int)bit != half) continue;
+    const size_t src = swap ? (I ^ ((size_t)1 << sel)) : I;
+    if (src >= v.size()) continue;
+    out[m] = W.empty() ? v[src] : mul(v[src], W[j]);
+  }
+  return out;
+}
+static FrVec hostTensorStep(const FrVec& W, const Fr& lo, const Fr& hi) {
+  const size_t len = W.empty() ? 1 : W.size();
+  FrVec out(2 * len);
+  for (size_t j = 0; j < len; j++) {
+    out[2 * j] = W.empty() ? lo : mul(W[j], lo);
+    out[2 * j + 1] = W.empty() ? hi : mul(W[j], hi);
+  }
+  return out;
+}
+static InnerProductProof innerArgProofFrozenHost(bn256_ctx* ctx, int N, const DevPoints& G, const DevPoints& H, const Point& U,
+                                                 FrVec a, FrVec b, InnerProductProof proof) {
+  const size_t Nf = (size_t)N;
+  FrVec WG, WH;
+  while (N != 1) {
+    const size_t n1 = (size_t)N / 2;
+    const int sel = ilog2((size_t)N) - 1;
+    FrVec alo = slice(a, 0, n1), ahi = slice(a, n1, N), blo = slice(b, 0, n1), bhi = slice(b, n1, N);
+    Fr cl = vectorMul(alo, bhi), cr = vectorMul(ahi, blo);
+    // the scalars of innerArgProofFrozen's six expanded vectors, made here; three MSMs over the whole frozen G, H
+    int tl = msmSegmentsSubmit(ctx, {{&G, 0, hostExpand(a, WG, Nf, (size_t)N, sel, true, 1)}, {&H, 0, hostExpand(b, WH, Nf, (size_t)N, sel, true, 0)}});
+    int tr = msmSegmentsSubmit(ctx, {{&G, 0, hostExpand(a, WG, Nf, (size_t)N, sel, true, 0)}, {&H, 0, hostExpand(b, WH, Nf, (size_t)N, sel, true, 1)}});
+    int tp = msmSegmentsSubmit(ctx, {{&G, 0, hostExpand(a, WG, Nf, (size_t)N, sel, false, 2)}, {&H, 0, hostExpand(b, WH, Nf, (size_t)N, sel, false, 2)}});
+    Point ul = fixedMult(U, cl), ur = fixedMult(U, cr), up = fixedMult(U, vectorMul(a, b));
+    Point L = pointAdd(msmWait(ctx, tl), ul);
+    Point R = pointAdd(msmWait(ctx, tr), ur);
+    Point P = pointAdd(msmWait(ctx, tp), up);
+    proof.L.push_back(L);
+    proof.R.push_back(R);
+    Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, L, R});
+    Fr xinv = fr_inv(x);
+    WG = hostTensorStep(WG, xinv, x);  // G' = xinv*G_lo + x*G_hi ; H' = x*H_lo + xinv*H_hi   (main.go:355-356)
+    WH = hostTensorStep(WH, x, xinv);
+    FrVec a1 = vectorAdd(vectorMulOnScalar(alo, x), vectorMulOnScalar(ahi, xinv));
+    FrVec b1 = vectorAdd(vectorMulOnScalar(bhi, x), vectorMulOnScalar(blo, xinv));
+    a = a1;
+    b = b1;
+    N = (int)n1;
+  }
+  proof.A = a[0];
+  proof.B = b[0];
+  return proof;
+}
 InnerProductProof innerArgProofFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, FrVec a, FrVec b,
                                       InnerProductProof proof) {
   const size_t Nf = (size_t)N;  // G, H stay as they are from here on
+  if (Nf <= ipaHostExpand()) return innerArgProofFrozenHost(ctx, N, G, H, U, std::move(a), std::move(b), std::move(proof));
   DevFr wG, wH;
   std::vector<DevFr> keep;
   while (N != 1) {
@@ -1273,6 +1336,8 @@ InnerProductProof innerArgProofFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoi
 std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H, const Point& U, Point P,
                                  const InnerProductProof& proof, size_t deep) {
   const size_t Nf = (size_t)N;
+  const bool host = Nf <= ipaHostExpand();  // the tensor of the challenges on the host (see innerArgProofFrozenHost)
+  FrVec WG, WH;
   DevFr wG, wH;
   std::vector<DevFr> keep;
   HostChain helper;
@@ -1280,7 +1345,11 @@ std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H
     if (deep >= proof.L.size() || deep >= proof.R.size()) return "failed to verify inner argument proof";
     Fr x = hashFS({fr_from_u64((uint64_t)N)}, {P, proof.L[deep], proof.R[deep]});
     Fr xinv = fr_inv(x), x2 = mul(x, x), x2inv = fr_inv(x2);
-    ipaStep(ctx, wG, wH, x, xinv, keep);  // enqueued only: the device works beside the host's P update
+    if (host) {
+      WG = hostTensorStep(WG, xinv, x);
+      WH = hostTensorStep(WH, x, xinv);
+    } else
+      ipaStep(ctx, wG, wH, x, xinv, keep);  // enqueued only: the device works beside the host's P update
     // x^2 L and x^-2 R (main.go:305-307) are the verifier's critical path -- 2 x ~85 us a level, and the next
     // challenge hashes the P they give -- so the second one runs on the helper thread
     Point rx;
@@ -1292,6 +1361,12 @@ std::string innerArgVerifyFrozen(bn256_ctx* ctx, int N, DevPoints G, DevPoints H
     deep++;
   }
   // com(G[0], H[0], a, b) + (a*b)*U  (main.go:275-279) with G[0] = <G_f, W_G>, H[0] = <H_f, W_H>: one MSM
+  if (host) {
+    if (WG.empty()) WG = WH = FrVec{kFrOne};  // N = 1 from the start
+    Point p = pointAdd(msmSegments(ctx, {{&G, 0, vectorMulOnScalar(WG, proof.A)}, {&H, 0, vectorMulOnScalar(WH, proof.B)}}),
+                       fixedMult(U, mul(proof.A, proof.B)));
+    return pointEq(P, p) ? "" : "failed to verify inner argument proof";
+  }
   FrVec one1 = {kFrOne};
   DevFr d1(ctx, one1);
   std::vector<DevFr> e = devTensorExpand(ctx, {{&d1, Nf, &wG, 0, false, proof.A, proof.A}, {&d1, Nf, &wH, 0, false, proof.B, proof.B}}, 1);

@@ -29,6 +29,24 @@ def test_transcript_identical_to_oracle(bp, golden, idx):
     assert bp.verify(t["n"], int(t["seed"], 16), raw) is None
 
 
+@pytest.mark.parametrize("idx", [1, 2], ids=["n8", "n64"])
+def test_transcript_identical_with_the_tensor_expansion_on_the_device(bp, golden, idx, monkeypatch):
+    """The inner-product argument over frozen generators makes its expanded scalar vectors on the host up to 512
+    generators and on the device above (bn256_fr_tensor_step_multi / _expand_multi); BP_IPA_HOST_EXPAND=0 sends
+    the fixtures' small proofs down the device's way too: the same bytes, and either verifier accepts either."""
+    from crypto_amd.bp import parse_proof
+    t = golden["bulletproofs"][idx]
+    seed = int(t["seed"], 16)
+    raw_host = bp.prove(t["n"], t["v"], seed)
+    monkeypatch.setenv("BP_IPA_HOST_EXPAND", "0")
+    raw_dev = bp.prove(t["n"], t["v"], seed)
+    assert raw_dev == raw_host
+    assert parse_proof(raw_dev)["L"] == t["proof"]["L"]
+    assert bp.verify(t["n"], seed, raw_host) is None
+    monkeypatch.delenv("BP_IPA_HOST_EXPAND")
+    assert bp.verify(t["n"], seed, raw_dev) is None
+
+
 def test_verify_rejects_with_reference_errors(bp, golden):
     t = golden["bulletproofs"][1]
     seed = int(t["seed"], 16)
