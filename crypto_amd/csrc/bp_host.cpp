@@ -981,7 +981,7 @@ struct DotArg {
   View vb;
   const Fr* mu;
 };
-void devDotMulti(bn256_ctx* ctx, const std::vector<DotArg>& d, Fr* out) {
+[[maybe_unused]] void devDotMulti(bn256_ctx* ctx, const std::vector<DotArg>& d, Fr* out) {
   const size_t k = d.size();
   std::vector<const bn256_frvec*> a(k), b(k);
   std::vector<size_t> ao(k), as(k), an(k), bo(k), bs(k), bn(k);
@@ -1432,6 +1432,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     DevFr dots;
     Fr y, roinv;
     std::vector<DevFr> keep;
+    std::vector<DevPoints> keepPts;  // a folding round's old generators, which its MSMs still read
   };
   std::deque<PendingRound> pending;
   // A collected round's vectors are released at the end: bn256_fr_free waits for EVERY lane that holds a call (it
@@ -1439,6 +1440,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
   // after it -- the rounds ran one after the other (kernel trace: the lanes' kernels never overlapped).  They are
   // the small rounds' vectors only (at most kFreeze elements each).
   std::vector<DevFr> retired;
+  std::vector<DevPoints> retiredPts;  // (bn256_bases_free joins the busy lanes as well)
   size_t rounds_done = 0;  // res.X belongs to the chain's thread while frozen rounds are being collected
   auto collect = [&]() {
     PendingRound pr = std::move(pending.front());
@@ -1451,6 +1453,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     const Fr y = pr.y, roinv_k = pr.roinv;
     retired.push_back(std::move(pr.dots));
     for (DevFr& x : pr.keep) retired.push_back(std::move(x));
+    for (DevPoints& x : pr.keepPts) retiredPts.push_back(std::move(x));
     chain.push([&C, &res, &gTable, d5, mx, mr, y, roinv_k] {  // C, res.X, res.R are read again only after chain.wait()
       const Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv_k)), add(d5[1], d5[2]));
       const Fr vr = add(d5[3], d5[4]);
@@ -1506,7 +1509,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
       // back to back and not waited for (the inner products are read when the round is collected).
       // two lanes per round; collected BEFORE this round's kernels are enqueued: reading a round's inner products
       // waits for this context's stream, which then holds nothing newer than the previous round's kernels
-      while (pending.size() >= BN256_ASYNC_LANES / 2) collect();
+      while (2 * pending.size() + 2 > BN256_ASYNC_LANES) collect();
       lap(PF_MSM);
       chk(bn256_ctx_fr_defer_sync(ctx, 1));
       struct DeferOff {
@@ -1568,6 +1571,17 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     // (docs_test.go:1294), so both folds -- ~0.5 ms latency chains of ~130 doublings whatever the length --
     // go to two lanes FIRST and run under the whole round instead of after it (9 of the 28 ms at
     // |l| = 2^20 were these chains, waited for at the end of every round).
+    // Folding rounds are collected late as well (round 3): X and R of round k are needed by nothing before the final
+    // check, so round k + 1's folds and commitments are submitted while round k's MSMs still run -- two lanes for
+    // the folds (free again when the round's fold waits return), two for the commitments (held until the round is
+    // collected): 2 * pending + 4 lanes.  The host waits only for the folds, whose output the next round reads.
+    while (2 * pending.size() + 4 > BN256_ASYNC_LANES) collect();
+    lap(PF_MSM);
+    chk(bn256_ctx_fr_defer_sync(ctx, 1));
+    struct DeferOff {
+      bn256_ctx* c;
+      ~DeferOff() { (void)bn256_ctx_fr_defer_sync(c, 0); }
+    } defer_off{ctx};
     uint8_t oneb[32], yb[32], rob[32];
     fr_to_be(oneb, kFrOne);
     fr_to_be(yb, y);
@@ -1579,41 +1593,32 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     chk(bn256_fold2_submit(ctx, H.h, H0.off, H0.len, H.h, H1.off, H1.len, 2, oneb, yb, &hn, &th));
     DevPoints Hn(ctx, hn);
     lap(PF_PTFOLD);
-    // the two commitments' MSMs go to the other two lanes; the round's inner products run on the
-    // context's own stream meanwhile (none of the three needs another's result)
-    int tx = devMsmFusedSubmit(ctx, {{&H, H0, &l, l1, nullptr}, {&H, H1, &l, l0, nullptr}, {&G, G0, &n, n1, &ro},
-                                     {&G, G1, &n, n0, &roinv}});
-    int tr = devMsmFusedSubmit(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
+    // the two commitments' MSMs go to two more lanes (their streams wait on the device for l, n of the last round's
+    // un-waited folds); the round's inner products and vector folds follow on the context's own stream
+    PendingRound pr;
+    pr.y = y;
+    pr.roinv = roinv;
+    pr.tx = devMsmFusedSubmit(ctx, {{&H, H0, &l, l1, nullptr}, {&H, H1, &l, l0, nullptr}, {&G, G0, &n, n1, &ro},
+                                    {&G, G1, &n, n0, &roinv}});
+    pr.tr = devMsmFusedSubmit(ctx, {{&H, H1, &l, l1, nullptr}, {&G, G1, &n, n1, nullptr}});
     lap(PF_MSM);
-    // the round's five inner products (docs_test.go:1297-1311) in one call: one wait, one copy
-    Fr d5[5];
-    devDotMulti(ctx, {{&n, n0, &n, n1, &mu2}, {&c, c0, &l, l1, nullptr}, {&c, c1, &l, l0, nullptr},
-                      {&n, n1, &n, n1, &mu2}, {&c, c1, &l, l1, nullptr}}, d5);
-    Fr vx = add(mul(d5[0], mul(fr_from_u64(2), roinv)), add(d5[1], d5[2]));
-    Fr vr = add(d5[3], d5[4]);
+    // the round's five inner products (docs_test.go:1297-1311), left in HBM until the round is collected
+    pr.dots = devDotMultiDev(ctx, {{&n, n0, &n, n1, &mu2}, {&c, c0, &l, l1, nullptr}, {&c, c1, &l, l0, nullptr},
+                                   {&n, n1, &n, n1, &mu2}, {&c, c1, &l, l1, nullptr}});
     lap(PF_DOT);
-    Point gx = gTable.mul(vx), gr = gTable.mul(vr);  // under the MSMs, which the lanes' threads are running
-    lap(PF_HOSTPT);
-    Point mx = devMsmWait(ctx, tx);
-    Point mr = devMsmWait(ctx, tr);
-    lap(PF_MSM);
-    Point X = pointAdd(gx, mx);
-    Point R = pointAdd(gr, mr);
-    lap(PF_HOSTPT);
-    res.X.push_back(X);
-    res.R.push_back(R);
-    // the three scalar-vector folds (one call) and the host's C' run while the generator folds finish
     DevFr c_, l_, n_;
     devFoldHalves3(ctx, c, kFrOne, y, l, kFrOne, y, n, roinv, y, c_, l_, n_);
     lap(PF_FRFOLD);
-    chain.push([&C, X, R, y] {  // C is read again only after chain.wait()
-      Point C_ = pointAdd(C, scalarMult(X, y));
-      C = pointAdd(C_, scalarMult(R, sub(mul(y, y), kFrOne)));
-    });
-    lap(PF_HOSTPT);
     chk(bn256_fold_wait(ctx, tg));
     chk(bn256_fold_wait(ctx, th));
     lap(PF_PTFOLD);
+    // the old generators and vectors live on with the round's record: its MSMs read them
+    pr.keepPts.push_back(std::move(G));
+    pr.keepPts.push_back(std::move(H));
+    pr.keep.push_back(std::move(c));
+    pr.keep.push_back(std::move(l));
+    pr.keep.push_back(std::move(n));
+    pending.push_back(std::move(pr));
     G = std::move(Gn);
     H = std::move(Hn);
     c = std::move(c_);
@@ -1621,7 +1626,7 @@ WnlaResult wnla(bn256_ctx* ctx, const Point& g, DevPoints G, DevPoints H, DevFr 
     mu = mu2;
     l = std::move(l_);
     n = std::move(n_);
-    lap(PF_HOSTPT);
+    lap(PF_OTHER);
   }
 }
 
