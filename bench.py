@@ -77,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip single_call / pcie / 2^24 / bulletproofs-like legs")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--depth", type=int, default=4, choices=[1, 2, 3, 4], help="MSM calls in flight per GPU")
+    ap.add_argument("--depth", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 7, 8], help="MSM calls in flight per GPU (at most BN256_ASYNC_LANES)")
     return ap.parse_args(argv)
 
 
