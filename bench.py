@@ -59,7 +59,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 IMAD_PER_POINT = 23120          # 17 windows x 10 modmul x 136 IMAD
-IMAD_PEAK = 3.47e13             # measured v_mad_u64_u32 lane-ops/s, profiles/r01_ubench_valu.txt
+# Measured multiply-add issue rate of the chip, lane-ops/s: one asm block of dependent v_mad_i64_i32, four waves per
+# SIMD, 1.714 ns per wave-instruction (tools/probe/vgpr_bank_probe.hip, profiles/r03_ubench_issue.txt) = 15.6 of the
+# nominal 16 lanes/clk/SIMD at 2.4 GHz.  Rounds 1 and 2 priced against 3.47e13 (profiles/r01_ubench_valu.txt: one
+# instruction per asm statement, which hipcc pads; 4.6 clk per instruction) -- kept as `frac_vs_r01_peak`.
+IMAD_PEAK = 3.82e13
+IMAD_PEAK_R01 = 3.47e13
 SEED_BASES, SEED_SCALARS = 0x5EED0001, 0x5EED0002
 N_ORDER = 0x8FB501E34AA387F9AA6FECB86184DC212E8D8E12F82B39241A2EF45B57AC7261
 
@@ -359,6 +364,8 @@ def worker(args) -> int:
                 "peak": IMAD_PEAK,
                 "unit": "IMAD/s",
                 "frac": achieved / IMAD_PEAK,
+                "frac_vs_r01_peak": achieved / IMAD_PEAK_R01,
+                "peak_source": "profiles/r03_ubench_issue.txt (rounds 1-2: 3.47e13, profiles/r01_ubench_valu.txt)",
                 "traffic": traffic,
                 "traffic_source": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
                 "executed_valu_lane_ops_per_point": executed,

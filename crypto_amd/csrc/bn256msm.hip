@@ -1220,12 +1220,25 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
     // empty buckets were initialised by the two-pass sort), by buckets otherwise
     const bool by_chunks = two && nbt > T;
     u32* lastb = by_chunks ? (u32*)ctx->ws[WS_LASTB] : (u32*)nullptr;
+    // wave priorities step down at these iterations of a chunk (k_accumulate), counted from its end: what is
+    // left after the last step is what the SIMD's waves finish one after the other, so the steps sit late --
+    // 24, 12 and 4 iterations before the end of a 52-entry chunk (swept with BN256_ACC_PRIO="a,b,c" on one box,
+    // tools/ab_prio.sh: quarters 0.802-0.804 ms, 24,12,4 0.790-0.792, 12,6,2 0.790-0.794, 6,3,1 0.811-0.815;
+    // without priorities 0.850)
+    u32 prio_steps;
+    {
+      static const char* env = getenv("BN256_ACC_PRIO");
+      unsigned a = (K * 15u) >> 5, bq = (K * 15u) >> 6, cq = K / 13u;
+      if (env) (void)sscanf(env, "%u,%u,%u", &a, &bq, &cq);
+      auto at = [&](unsigned back) { return (u32)std::min<u32>(255u, K > back ? K - back : 0u); };
+      prio_steps = at(a) | (at(bq) << 8) | (at(cq) << 16);
+    }
     if (b->no_inf)
       hipLaunchKernelGGL(k_accumulate<true>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
+                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb, prio_steps);
     else
       hipLaunchKernelGGL(k_accumulate<false>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb);
+                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb, prio_steps);
     MSM_MARK(4);
     if (by_chunks)
       hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(std::min<size_t>(T, 262144), 256)), dim3(256), 0, s,

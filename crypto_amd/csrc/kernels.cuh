@@ -920,7 +920,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
                                                     const u32* __restrict__ offsets, u32 nbt, u32 K, u32 add_prev,
                                                     xyzz_mem* __restrict__ buckets,
                                                     xyzz_mem* __restrict__ partials, const u32* __restrict__ flags,
-                                                    u32* __restrict__ lastb) {
+                                                    u32* __restrict__ lastb, u32 prio_steps) {
   // an oversized group that no split kernel handled left part of sval[] unwritten: do not gather through
   // it (the host repeats the call with the split kernels, msm_finish)
   if (flags[0] & MSM_FLAG_OVERSIZED) return;
@@ -942,7 +942,20 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
   xyzz acc;
   xyzz_set_inf(acc);
   if (add_prev && !head) xyzz_load(acc, &buckets[cur]);
-  for (u32 e = start; e < end; e++) {
+  // The four waves of a SIMD are served oldest first, so left alone they finish one after the other -- a quarter
+  // of the kernel runs with ONE wave per SIMD (PMC: mean occupancy 10 of 16 waves per CU, wave lifetime 63 % of
+  // the kernel = (1 + 2 + 3 + 4) / 16), at a lone wave's issue rate and with its memory waits exposed.  Every wave
+  // therefore starts at the highest priority and steps down as it gets through its chunk: whoever is behind is
+  // served first, the four stay within a quarter of a chunk of each other and finish together.
+  // prio_steps: the three step-down points as iterations (bytes 0..2; see the launch in bn256msm.hip)
+  const u32 s1 = prio_steps & 255u, s2 = (prio_steps >> 8) & 255u, s3 = (prio_steps >> 16) & 255u;
+  __builtin_amdgcn_s_setprio(3);
+  for (u32 i = 0; i < K; i++) {
+    if (i == s1) __builtin_amdgcn_s_setprio(2);
+    if (i == s2) __builtin_amdgcn_s_setprio(1);
+    if (i == s3) __builtin_amdgcn_s_setprio(0);
+    const u32 e = start + i;
+    if (e >= end) break;
     u32 val = sval[e];
     if (e >= bend) {
       xyzz_store(head ? &partials[2 * (size_t)t] : &buckets[cur], acc);
@@ -1243,6 +1256,7 @@ __global__ void __launch_bounds__(256) k_fold_lane2(xyzz_mem* __restrict__ bucke
     const u32 rem = (u32)(tid % per_set);
     const u32 row = rem / q, i = rem % q;
     xyzz_mem* p = buckets + (size_t)set * nb + (row == 0 ? 0u : (nb >> row)) + i;
+    // (wave priorities stepping down with progress, as in k_accumulate, were measured here: no change)
     xyzz c, d, r, a;
     xyzz_load(c, p + h);
     xyzz_load(d, p + h + q);

@@ -45,7 +45,8 @@ L.append("|---|---|")
 L.append(f"| `value`: {bench['config'].get('calls_in_flight', 3)} calls in flight ({bench['config'].get('hw_queues', 4)} hardware queues), scalars resident | **{bench['value'] / 1e6:.0f} Mpts/s** ({bench['ms_per_step']:.3f} ms per step, whole-MSM fraction {rf['whole_msm_frac']:.3f}) |")
 L.append(f"| `single_call`: one blocking `bn256_msm_dev`, median of {sc['calls']} | {sc['median_ms']:.3f} ms = {sc['points_per_s'] / 1e6:.0f} Mpts/s, whole-MSM fraction **{sc['whole_msm_frac']:.3f}** |")
 L.append(f"| phases of a blocking call (HIP events, ms) | pass A {ph['sort_pass_a']:.3f}, pass B {ph['sort_pass_b']:.3f}, accumulate {ph['accumulate']:.3f}, fix {ph['fix']:.3f}, reduce {ph['reduce']:.3f}, device total {ph['device_total']:.3f} |")
-L.append(f"| `roofline` (`k_accumulate`, 2²⁰ × 23 120 IMAD per launch) | {rf['kernel_ms']:.3f} ms → {rf['achieved']:.3e} IMAD/s = **{rf['frac']:.3f}** of {rf['peak']:.2e} |")
+L.append(f"| `roofline` (`k_accumulate`, 2²⁰ × 23 120 IMAD per launch) | {rf['kernel_ms']:.3f} ms → {rf['achieved']:.3e} IMAD/s = **{rf['frac']:.3f}** of {rf['peak']:.2e}" +
+         (f" ({rf['frac_vs_r01_peak']:.3f} of the 3.47e13 that rounds 1 and 2 priced against)" if 'frac_vs_r01_peak' in rf else "") + " |")
 if "k_accumulate<true>" in d1:
     L.append(f"| rocprofv3 kernel-trace average of `k_accumulate`, `--depth 1` / default command | {d1['k_accumulate<true>'][1] / 1e3:.3f} ms over {d1['k_accumulate<true>'][0]} launches / {d3['k_accumulate<true>'][1] / 1e3:.3f} ms over {d3['k_accumulate<true>'][0]} |")
 L.append(f"| `k_accumulate` PMC per launch | `SQ_INSTS_VALU` {acc['SQ_INSTS_VALU'] / 1e6:.1f} M = {acc['SQ_INSTS_VALU'] * 64 / adds:.0f} per addition, {acc['SQ_INSTS_VALU'] * 64 / n:.0f} lane-ops per point (canonical 23 120: ×{acc['SQ_INSTS_VALU'] * 64 / n / 23120:.2f}); FETCH {acc['FETCH_SIZE_KB'] * 1024 / 1e9:.2f} GB + WRITE {acc['WRITE_SIZE_KB'] * 1024 / 1e9:.2f} GB = `traffic` {rf['traffic'] / 1e9:.2f} GB ({rf['traffic'] / (rf['kernel_ms'] * 1e-3) / 1e12:.2f} TB/s) |")
