@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -206,6 +207,10 @@ struct bn256_ctx {
   struct lane_worker* worker[BN256_ASYNC_LANES];  // the lane's host thread: enqueue, wait and host tail of a submitted call
   struct lane_ticket* pending[BN256_ASYNC_LANES];
   hipEvent_t lane_ev[BN256_ASYNC_LANES];  // orders a submitted call behind this context's deferred Fr kernels (lane_start)
+  // calls submitted to this context's lanes and not finished yet; a lane's context points at its parent's counter
+  // (`peers`), so a call can tell whether it has the chip to itself (k_accumulate's wave priorities, msm enqueue)
+  std::atomic<int> lanes_inflight{0};
+  std::atomic<int>* peers = nullptr;
   // bn256_ctx_create_multi: this context is only the parent of nshard ordinary contexts, one per
   // entry of the device list (it has no stream or workspace of its own)
   int nshard;
@@ -763,6 +768,7 @@ static int lane_acquire(bn256_ctx* ctx, int* out) {
   ctx->lane[l]->tune_c = ctx->tune_c;
   ctx->lane[l]->tune_k = ctx->tune_k;
   ctx->lane[l]->phase_timing = ctx->phase_timing;
+  ctx->lane[l]->peers = &ctx->lanes_inflight;
   *out = l;
   return BN256_OK;
 }
@@ -787,15 +793,17 @@ static int lane_start(bn256_ctx* ctx, int l, bool fold, std::function<int(bn256_
       return BN256_EHIP;
     }
   }
+  ctx->lanes_inflight.fetch_add(1, std::memory_order_relaxed);
   {
     std::lock_guard<std::mutex> lk(w->mu);
     w->busy = true;
-    w->job = [lane, t, fn] {
+    w->job = [ctx, lane, t, fn] {
       g_hip_msg[0] = 0;
       t->rc = fn(lane, t);
       if (t->rc) (void)hipStreamSynchronize(lane->stream);  // whatever was enqueued has left the workspaces
       memcpy(t->msg, g_hip_msg, sizeof t->msg);
       memcpy(t->ms, lane->last_ms, sizeof t->ms);
+      ctx->lanes_inflight.fetch_sub(1, std::memory_order_relaxed);
     };
   }
   w->cv.notify_all();
@@ -1224,14 +1232,25 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
     // left after the last step is what the SIMD's waves finish one after the other, so the steps sit late --
     // 24, 12 and 4 iterations before the end of a 52-entry chunk (swept with BN256_ACC_PRIO="a,b,c" on one box,
     // tools/ab_prio.sh: quarters 0.802-0.804 ms, 24,12,4 0.790-0.792, 12,6,2 0.790-0.794, 6,3,1 0.811-0.815;
-    // without priorities 0.850)
+    // without priorities 0.850).  Only for a call that has the chip to itself: with other calls of this context
+    // in flight their kernels fill the SIMDs that this one's last waves leave, and young accumulation waves served
+    // before another call's old ones cost throughput (tools/ab_prio_tp.sh: four calls in flight 885 -> 856 Mpts/s
+    // with the steps, one call 1.265 -> 1.21 ms; priorities RISING with progress, so that a call's last waves leave
+    // sooner, cost as much: 950 -> 912-946 by where the steps sit) -- then every wave runs at priority 0 from the
+    // start, below the sort and the tail kernels (SMALL_PRIO, kernels.cuh).
     u32 prio_steps;
     {
       static const char* env = getenv("BN256_ACC_PRIO");
+      static const char* env_always = getenv("BN256_ACC_PRIO_ALWAYS");  // experiments: 1 = also with calls in flight, 0 = never
+      const int others = ctx->peers ? ctx->peers->load(std::memory_order_relaxed) - 1
+                                    : ctx->lanes_inflight.load(std::memory_order_relaxed);
+      const bool alone = env_always ? env_always[0] == '1' : others <= 0;
       unsigned a = (K * 15u) >> 5, bq = (K * 15u) >> 6, cq = K / 13u;
       if (env) (void)sscanf(env, "%u,%u,%u", &a, &bq, &cq);
+      if (!alone) a = bq = cq = K;
       auto at = [&](unsigned back) { return (u32)std::min<u32>(255u, K > back ? K - back : 0u); };
       prio_steps = at(a) | (at(bq) << 8) | (at(cq) << 16);
+
     }
     if (b->no_inf)
       hipLaunchKernelGGL(k_accumulate<true>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,

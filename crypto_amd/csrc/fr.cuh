@@ -133,6 +133,12 @@ __device__ __forceinline__ fr fr_from_arg(const fr_arg& a) {
   return r;
 }
 
+// wave priority of the Fr kernels (experiments; 3 beside the MSM's sort and tail kernels changed neither WNLA nor go/bp)
+#ifndef FR_PRIO
+#define FR_PRIO 0
+#endif
+#define FR_KERNEL_PRIO() do { if (FR_PRIO) __builtin_amdgcn_s_setprio(FR_PRIO); } while (0)
+
 // out[i] = s_a * a[a_off + i*stride] + s_b * b[b_off + i*stride]; an index past n_a / n_b reads 0
 // (BP++'s pad-tolerant vectorAdd, go/bppp/util.go:245-260; IPA halves go/bp/main.go:357-358;
 // WNLA l' = l0 + y l1, n' = rho^-1 n0 + y n1, go/bppp/docs_test.go:1318-1319).
@@ -150,6 +156,7 @@ struct fr_fold_batch {
   fr_fold_desc d[FR_BATCH];
 };
 __global__ void __launch_bounds__(256) k_fr_fold(fr_fold_batch batch) {
+  FR_KERNEL_PRIO();
   const fr_fold_desc& D = batch.d[blockIdx.y];
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D.n) return;
@@ -177,6 +184,7 @@ struct fr_dot_batch {
   fr_dot_desc d[FR_DOT_BATCH];
 };
 __global__ void __launch_bounds__(256) k_fr_dot(fr_dot_batch batch) {
+  FR_KERNEL_PRIO();
   __shared__ fr lds[256];
   const fr_dot_desc& D = batch.d[blockIdx.y];
   if (blockIdx.x >= D.nblk) return;  // uniform over the workgroup
@@ -222,6 +230,7 @@ __global__ void __launch_bounds__(256) k_fr_dot(fr_dot_batch batch) {
 }
 // one workgroup per product: out_be[32 * blockIdx.x ..] = sum of its partials
 __global__ void __launch_bounds__(256) k_fr_sum(fr_dot_batch batch, uint8_t* __restrict__ out_be) {
+  FR_KERNEL_PRIO();
   __shared__ fr lds[256];
   const fr_dot_desc& D = batch.d[blockIdx.x];
   fr acc = fr_zero();
@@ -254,6 +263,7 @@ struct fr_step_batch {
   fr_step_desc d[FR_BATCH];
 };
 __global__ void __launch_bounds__(256) k_fr_tensor_step(fr_step_batch batch, u32 layout) {
+  FR_KERNEL_PRIO();
   const fr_step_desc& D = batch.d[blockIdx.y];
   u32 m = blockIdx.x * blockDim.x + threadIdx.x;
   const u32 len = D.len;
@@ -284,6 +294,7 @@ struct fr_expand_batch {
   fr_expand_desc d[FR_BATCH];
 };
 __global__ void __launch_bounds__(256) k_fr_tensor_expand(fr_expand_batch batch, u32 layout) {
+  FR_KERNEL_PRIO();
   const fr_expand_desc& D = batch.d[blockIdx.y];
   u32 m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= D.n_out) return;
@@ -317,6 +328,7 @@ struct gather_batch {
 };
 // up to GATHER_BATCH segments per launch (blockIdx.y): the WNLA X commitment has four
 __global__ void __launch_bounds__(256) k_gather_segment(gather_batch batch) {
+  FR_KERNEL_PRIO();
   const gather_desc& D = batch.d[blockIdx.y];
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= D.n) return;

@@ -23,6 +23,24 @@
 #pragma once
 #include "g1.cuh"
 #include "fr.cuh"
+// Wave priorities (s_setprio, 0..3; a SIMD issues from its highest-priority ready wave, oldest first among equals).
+// With several calls on the chip (bn256_msm_submit lanes, bench.py keeps four in flight) the kernels of one call's
+// sort and tail are short dependent chains beside another call's accumulation, which can use every issue slot it
+// is given: left at equal priority the chains wait their turn behind 2000-instruction loop bodies and every call
+// takes longer to leave its lane.  Tail kernels (fix-up, folds, packing) run at 3, sort kernels at 2, k_accumulate
+// at 0 (or stepping 3 -> 0 when the call is alone, below): four calls in flight 872-885 -> 926-947 Mpts/s on one
+// box (tools/ab_prio_tp.sh; 1, 2 or 3 for either class measured the same within 1 %, tail-only 910, none 880).
+#ifndef ACC_PRIO_BASE
+#define ACC_PRIO_BASE 3
+#endif
+#ifndef SMALL_PRIO
+#define SMALL_PRIO 3
+#endif
+#ifndef SORT_PRIO
+#define SORT_PRIO 2
+#endif
+#define SMALL_KERNEL_PRIO() do { if (SMALL_PRIO) __builtin_amdgcn_s_setprio(SMALL_PRIO); } while (0)
+#define SORT_KERNEL_PRIO() do { if (SORT_PRIO) __builtin_amdgcn_s_setprio(SORT_PRIO); } while (0)
 
 #define NOKEY 0xffffffffu
 
@@ -252,6 +270,7 @@ __global__ void __launch_bounds__(1024) k_tile_sort(const uint8_t* __restrict__ 
                                                     u32 sc_stride, u32 top_scale, u32* __restrict__ hist,
                                                     const u32* __restrict__ offsets, u32* __restrict__ sval,
                                                     u32* __restrict__ heavy_count, u32 first_pass) {
+  SORT_KERNEL_PRIO();
   extern __shared__ u32 lds[];
   const u32 tile = blockIdx.x, set = blockIdx.y, ntiles = gridDim.x;
   if (!SCATTER && tile == 0 && set == 0) heavy_clear(heavy_count, nullptr, first_pass);
@@ -363,6 +382,7 @@ __global__ void __launch_bounds__(1024) k_part(const uint8_t* __restrict__ scala
                                                u32* __restrict__ heavy_count, u32* __restrict__ gtotal_next,
                                                u32 first_pass) {
   extern __shared__ u32 lds[];  // cnt[G], cur[G], then per-wave histograms [16][G] aliased by stage[TCAP]
+  SORT_KERNEL_PRIO();
   constexpr u32 c = C;
   const u32 tile = blockIdx.x, wave = threadIdx.x >> 6;
   if (tile == 0) heavy_clear(heavy_count, gtotal_next, first_pass);
@@ -444,6 +464,7 @@ __global__ void __launch_bounds__(1024) k_group_sort(const u32* __restrict__ rec
                                                      u32* __restrict__ offsets, u32* __restrict__ sval,
                                                      xyzz_mem* __restrict__ buckets, u32 init_inf,
                                                      u32* __restrict__ flags) {
+  SORT_KERNEL_PRIO();
   extern __shared__ u32 lds[];
   __shared__ u32 sh_gs, sh_m;
   const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -552,6 +573,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
                                                         u32 level_stride, u32* __restrict__ offsets,
                                                         u32* __restrict__ sval, xyzz_mem* __restrict__ buckets,
                                                         u32 init_inf, u32* __restrict__ flags) {
+  SORT_KERNEL_PRIO();
   // ntiles: tiles of pass A (a multiple of SORT2_S, the last ones may be empty); ntiles_data: those with scalars
   extern __shared__ u32 lds[];
   __shared__ u32 sh_gs, sh_m;
@@ -677,6 +699,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
 __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec, const u32* __restrict__ loc,
                                                      const u32* __restrict__ gtotal, u32 G, u32 TS, u32 LB, u32 cap,
                                                      u32* __restrict__ subhist) {
+  SORT_KERNEL_PRIO();
   extern __shared__ u32 lds[];  // h[4][B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S, wave = threadIdx.x >> 6;
@@ -697,6 +720,7 @@ __global__ void __launch_bounds__(256) k_group_count(const u32* __restrict__ rec
 __global__ void __launch_bounds__(1024) k_group_subscan(const u32* __restrict__ gtotal, u32 LB, u32 cap,
                                                         u32* __restrict__ subhist, u32* __restrict__ offsets,
                                                         xyzz_mem* __restrict__ buckets, u32 init_inf) {
+  SORT_KERNEL_PRIO();
   __shared__ u32 tmp[1024];
   __shared__ u32 sh_gs;
   const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, b = threadIdx.x;
@@ -727,6 +751,7 @@ __global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec
                                                      u32 G, u32 TS, u32 LB, u32 ibits, u32 base_off, u32 pt_stride,
                                                      u32 level_stride, u32 cap, u32 tile_local,
                                                      u32* __restrict__ sval) {
+  SORT_KERNEL_PRIO();
   extern __shared__ u32 cur[];  // [B]
   const u32 B = 1u << LB;
   const u32 g = blockIdx.x / SORT2_S, sp = blockIdx.x % SORT2_S;
@@ -753,6 +778,7 @@ __global__ void __launch_bounds__(256) k_group_place(const u32* __restrict__ rec
 // thread per (set, bucket): exclusive prefix of hist over tiles (in place) and the bucket total
 __global__ void __launch_bounds__(256) k_tile_scan(u32* __restrict__ hist, u32 nsets, u32 ntiles, u32 nb,
                                                    u32* __restrict__ totals) {
+  SORT_KERNEL_PRIO();
   u32 id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= nsets * nb) {
     if (id == nsets * nb) totals[id] = 0;  // sentinel so that the scan yields offsets[nbt] = total
@@ -788,6 +814,7 @@ __global__ void __launch_bounds__(256) k_recode(const uint8_t* __restrict__ scal
                                                 u32 sc_stride, u32 top_scale, u32* __restrict__ counts,
                                                 u32* __restrict__ rank,
                                                 const u32* __restrict__ offsets, u32* __restrict__ sval) {
+  SORT_KERNEL_PRIO();
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 k[8];
@@ -834,6 +861,7 @@ __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& to
 
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const u32* __restrict__ in, u32* __restrict__ out, u32 n,
                                                       u32* __restrict__ blocksum) {
+  SORT_KERNEL_PRIO();
   __shared__ u32 lds[256];
   u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   u32 v[SCAN_ITEMS];
@@ -854,6 +882,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan1(const u32* __restrict__ in
 }
 // single block: exclusive scan of blocksum[0..nblk) in place; writes grand total to *total_out
 __global__ void __launch_bounds__(256) k_scan2(u32* __restrict__ blocksum, u32 nblk, u32* __restrict__ total_out) {
+  SORT_KERNEL_PRIO();
   __shared__ u32 lds[256];
   u32 per = (nblk + 255) / 256;
   u32 lo = threadIdx.x * per;
@@ -872,6 +901,7 @@ __global__ void __launch_bounds__(256) k_scan2(u32* __restrict__ blocksum, u32 n
   if (threadIdx.x == 0) *total_out = total;
 }
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32 n, const u32* __restrict__ blocksum) {
+  SORT_KERNEL_PRIO();
   u32 add = blocksum[blockIdx.x];
   u32 base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
 #pragma unroll
@@ -884,6 +914,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan3(u32* __restrict__ out, u32
 #define SCAN_SMALL_ITEMS 16
 #define SCAN_SMALL_MAX (1024 * SCAN_SMALL_ITEMS)
 __global__ void __launch_bounds__(1024) k_scan_small(const u32* __restrict__ in, u32* __restrict__ out, u32 n) {
+  SORT_KERNEL_PRIO();
   __shared__ u32 tmp[1024];
   const u32 base = threadIdx.x * SCAN_SMALL_ITEMS;
   u32 v[SCAN_SMALL_ITEMS];
@@ -947,12 +978,13 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
   // the kernel = (1 + 2 + 3 + 4) / 16), at a lone wave's issue rate and with its memory waits exposed.  Every wave
   // therefore starts at the highest priority and steps down as it gets through its chunk: whoever is behind is
   // served first, the four stay within a quarter of a chunk of each other and finish together.
-  // prio_steps: the three step-down points as iterations (bytes 0..2; see the launch in bn256msm.hip)
+  // prio_steps: the three step-down points as iterations (bytes 0..2; see the launch in bn256msm.hip, which puts
+  // all three at iteration 0 -- priority 0 throughout -- when other calls of the context are in flight)
   const u32 s1 = prio_steps & 255u, s2 = (prio_steps >> 8) & 255u, s3 = (prio_steps >> 16) & 255u;
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(ACC_PRIO_BASE);
   for (u32 i = 0; i < K; i++) {
-    if (i == s1) __builtin_amdgcn_s_setprio(2);
-    if (i == s2) __builtin_amdgcn_s_setprio(1);
+    if (i == s1) __builtin_amdgcn_s_setprio(ACC_PRIO_BASE > 1 ? ACC_PRIO_BASE - 1 : 0);
+    if (i == s2) __builtin_amdgcn_s_setprio(ACC_PRIO_BASE > 2 ? ACC_PRIO_BASE - 2 : 0);
     if (i == s3) __builtin_amdgcn_s_setprio(0);
     const u32 e = start + i;
     if (e >= end) break;
@@ -1007,6 +1039,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 k_fix_boundary(const u32* __restrict__ offsets, u32 nbt, u32 K, const u32* __restrict__ lastb,
                xyzz_mem* __restrict__ buckets, const xyzz_mem* __restrict__ partials, u32* __restrict__ heavy_count,
                u32* __restrict__ heavy_list, const u32* __restrict__ flags) {
+  SMALL_KERNEL_PRIO();
   if (flags[0] & MSM_FLAG_OVERSIZED) return;
   const u32 M = offsets[nbt];
   const u32 nchunks = M / K + (M % K ? 1u : 0u), step = gridDim.x * blockDim.x;
@@ -1051,6 +1084,7 @@ __global__ void __launch_bounds__(64) k_bucket_fix(const u32* __restrict__ offse
                                                    const xyzz_mem* __restrict__ partials,
                                                    u32* __restrict__ heavy_count, u32* __restrict__ heavy_list,
                                                    const u32* __restrict__ flags) {
+  SMALL_KERNEL_PRIO();
   // an oversized group that no split kernel handled left part of offsets[] unwritten: chunk numbers
   // derived from it would index partials[] out of bounds (the host repeats the call, msm_finish)
   if (flags[0] & MSM_FLAG_OVERSIZED) return;
@@ -1129,6 +1163,7 @@ __global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, 
                                                xyzz_mem* __restrict__ buckets,
                                                const xyzz_mem* __restrict__ partials, u32* __restrict__ heavy_count,
                                                const u32* __restrict__ heavy_list, xyzz_mem* __restrict__ tmp) {
+  SMALL_KERNEL_PRIO();
   __shared__ xyzz_mem sh[64];
   __shared__ u32 ticket;
   const u32 nmed = heavy_count[HEAVY_MEDIUM];
@@ -1191,6 +1226,7 @@ __global__ void __launch_bounds__(256) k_heavy(const u32* __restrict__ offsets, 
 // Level l (width w = nb >> l) folds the main row [0,w) and the l rows at bases nb>>j
 // (j = 1..l) in half: B[base+i] += B[base+i+w/2].  After c-1 levels T = B[0], G_k = B[2^k].
 __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  SMALL_KERNEL_PRIO();
   // one quad per output element (quad-cooperative addition, see g1.cuh)
   u32 half = (nb >> level) >> 1;
   u32 rows = level + 1;
@@ -1219,6 +1255,7 @@ __global__ void __launch_bounds__(64) k_fold(xyzz_mem* __restrict__ buckets, u32
 // coalesced 16-byte accesses instead of nine strided loads per lane changed nothing: measured).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_fold_lane(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  SMALL_KERNEL_PRIO();
   u32 half = (nb >> level) >> 1;
   u32 rows = level + 1;
   u64 per_set = (u64)rows * half;
@@ -1247,6 +1284,7 @@ k_fold_lane(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
 // additions in the other rows), and a lane's next operands load while it computes -- the one-addition
 // kernel's waves all load, then all compute, then all store.
 __global__ void __launch_bounds__(256) k_fold_lane2(xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb, u32 level) {
+  SMALL_KERNEL_PRIO();
   const u32 h = (nb >> level) >> 1, q = h >> 1;
   const u32 rows = level + 1;
   const u64 per_set = (u64)rows * q;
@@ -1297,6 +1335,7 @@ __device__ __forceinline__ void pack_point(u32* __restrict__ o, const xyzz_mem* 
 // workgroup needs two or three rounds for the wider levels.)
 __global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb,
                                                      u32 q, u32* __restrict__ out, const u32* __restrict__ flags) {
+  SMALL_KERNEL_PRIO();
   u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid == 0) {
     out[(size_t)nsets * (q + 1) * 32] = flags[0];
@@ -1316,6 +1355,7 @@ __global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict_
 __global__ void __launch_bounds__(768) k_fold_small(xyzz_mem* buckets, u32 nsets, u32 nb, u32 q, u32* __restrict__ out,
                                                     const u32* __restrict__ flags) {
   const u32 set = blockIdx.x;
+  SMALL_KERNEL_PRIO();
   xyzz_mem* B = buckets + (size_t)set * nb;
   const u32 quad = threadIdx.x >> 2, role = threadIdx.x & 3u, nquads = blockDim.x >> 2;
   for (u32 l = 0; l < q; l++) {
