@@ -1025,6 +1025,8 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   auto pick_k = [&](size_t m) -> u32 {
     unsigned long long e = (unsigned long long)m * W;
     if (ctx->tune_k) return (u32)ctx->tune_k;
+    static const int env_k = getenv("BN256_TUNE_K") ? atoi(getenv("BN256_TUNE_K")) : 0;  // experiments
+    if (env_k > 0 && e > (1ull << 22)) return (u32)env_k;
     // >= 2^18 threads when there is work for them (rounded up: 2^18 threads are one round of waves, a
     // 2^18 + 1st thread would run alone after them).  Up to 2^19 entries the whole call is latency: a thread's K
     // mixed additions are a serial chain of ~7 us each (a lone wave), and a bucket of b entries then needs
