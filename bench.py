@@ -351,6 +351,7 @@ def worker(args) -> int:
             "single_call": {"calls": nblk, "median_ms": med * 1e3, "mean_ms": dt_blocking / nblk * 1e3,
                             "points_per_s": n_total / med if med == med else None,
                             "whole_msm_frac": (n * IMAD_PER_POINT / med) / IMAD_PEAK if med == med else None,
+                            "whole_msm_frac_vs_r01_peak": (n * IMAD_PER_POINT / med) / IMAD_PEAK_R01 if med == med else None,
                             "same_result": bool(result_blocking == result)},
             "roofline": {
                 "bound": "valu_int",
@@ -370,6 +371,7 @@ def worker(args) -> int:
                 "traffic_source": os.path.relpath(pmc_file, ROOT) if pmc_file else None,
                 "executed_valu_lane_ops_per_point": executed,
                 "whole_msm_frac": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK,
+                "whole_msm_frac_vs_r01_peak": (n * IMAD_PER_POINT / (dt / steps)) / IMAD_PEAK_R01,
             },
         }
         if not args.no_precompute and n >= (1 << 18) and n <= (1 << 21) and not args.window_bits:
