@@ -1,6 +1,10 @@
 #!/bin/bash
 # Round 2's tree (ab/r2tree: `git archive 9c7408f`, built with its own crypto_amd/build.py) against this tree on ONE
 # box: each round's own default bench.py, alternating, plus its WNLA and go/bp tools.  Lines go to gpurun_out/ab_rounds_*.
+# Here, first (ab/ is git-ignored):
+#   mkdir -p ab/r2tree && git archive 9c7408f | tar -x -C ab/r2tree
+#   (cd ab/r2tree && python -m crypto_amd.build && python -c "import __graft_entry__ as g; g.build()")
+# then `gpurun -- bash tools/ab_rounds.sh` and, here, `python tools/ab_rounds_report.py`.
 set -e -o pipefail
 O=$PWD/gpurun_out
 rm -f $O/ab_rounds_r2.jsonl $O/ab_rounds_r3.jsonl $O/ab_rounds_flows.txt
