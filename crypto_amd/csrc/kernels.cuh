@@ -1332,7 +1332,10 @@ __device__ __forceinline__ void pack_point(u32* __restrict__ o, const xyzz_mem* 
 // (Folding the last ten levels of a 2^19-bucket reduction and this packing into one workgroup-resident
 // launch was measured: 99 us against 65 + 8 us for the launches.  A level is a quad addition's latency,
 // ~5 us for a lone wave that issues one v_mad_i64_i32 per ~9.6 clk, not launch overhead, and a single
-// workgroup needs two or three rounds for the wider levels.)
+// workgroup needs two or three rounds for the wider levels.  Round 3, the same question from the other side: two
+// narrow levels per launch with sixteen lanes per item -- quads 0..2 add a + c, b + d, c + d side by side, quad 0
+// takes b + d over a DPP row shift and adds -- gave the same 0.206-0.209 ms for the reduction as fifteen single
+// levels: two dependent quad additions cost what two launches of one cost.)
 __global__ void __launch_bounds__(64) k_pack_results(const xyzz_mem* __restrict__ buckets, u32 nsets, u32 nb,
                                                      u32 q, u32* __restrict__ out, const u32* __restrict__ flags) {
   SMALL_KERNEL_PRIO();
