@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
   SORT_KERNEL_PRIO();
   // ntiles: tiles of pass A (a multiple of SORT2_S, the last ones may be empty); ntiles_data: those with scalars
   extern __shared__ u32 lds[];
-  __shared__ u32 sh_gs, sh_m;
+  __shared__ u32 sh_gs, sh_m, sh_far;
   const u32 B = 1u << LB, G = gridDim.x, g = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   u32* wcnt = lds;
   u32* cur = lds + NH * B;
@@ -584,6 +584,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
   u32* tile_a = tmp + 1024;
   u32* run_end = tile_a + 1024;
   u32* stage = run_end + 1024;
+  if (threadIdx.x == 0) sh_far = 0;
   u32 tot = threadIdx.x < G ? gtotal[threadIdx.x] : 0;
   u32 pre = block_exclusive_scan(tot, G, tmp);
   if (threadIdx.x == g) {
@@ -605,6 +606,7 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
   }
   (void)block_exclusive_scan(len, ntiles, tmp);  // tmp[t] = end of tile t's run afterwards
   if (threadIdx.x < 1024) run_end[threadIdx.x] = threadIdx.x < ntiles ? tmp[threadIdx.x] : m;
+  const u32 tagmask = LB == 10 ? 0xfc000000u : 0u;  // 26-bit records (13 windows, 1024 keys a group): the host's only use
   for (u32 t0 = wave; t0 < ntiles; t0 += 16 * 8) {
     u32 beg[8], len8[8], v[8];
     const u32* src[8];
@@ -622,12 +624,14 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
     }
 #pragma unroll
     for (u32 u = 0; u < 8; u++) v[u] = lane < len8[u] ? src[u][lane] : 0u;
+    // a record is 26 bits (window, index in the tile, sign, 10 key bits): the six above them take the tile number
+    // mod 64, from which the decoding below gets the tile back without looking at run_end[]
 #pragma unroll
     for (u32 u = 0; u < 8; u++)
-      if (lane < len8[u]) stage[beg[u] + lane] = v[u];
+      if (lane < len8[u]) stage[beg[u] + lane] = v[u] | ((((t0 + 16 * u) & 63u) << 26) & tagmask);
 #pragma unroll
     for (u32 u = 0; u < 8; u++)
-      for (u32 j = lane + 64; j < len8[u]; j += 64) stage[beg[u] + j] = src[u][j];
+      for (u32 j = lane + 64; j < len8[u]; j += 64) stage[beg[u] + j] = src[u][j] | ((((t0 + 16 * u) & 63u) << 26) & tagmask);
   }
   for (u32 j = threadIdx.x; j < NH * B; j += blockDim.x) wcnt[j] = 0;
   __syncthreads();
@@ -637,23 +641,35 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
   // ahead for a pass of 547 tiles padded to 576, and four records in five fell back to the search -- pass B
   // 126 us against 73 us for 7 % more records)
   const float tiles_per_record = m ? (float)ntiles_data / (float)m : 0.f;
+  // tile of the record at place e = first t with run_end[t] > e.  Uniform scalars give every tile the same share of
+  // the group, so g(e) = e * ntiles / m is right to within a tile or two, and the tile is the number within 31 of
+  // g(e) that has the six bits stored with the record: a handful of instructions, no LDS read (a walk along
+  // run_end[] from the guess was ~40 instructions a record, and this kernel is half issue-bound: 16 waves x 2650
+  // VALU instructions a workgroup).  Whether "within 31" holds is checked per RUN, at both its ends (g is
+  // monotonic): if any run of the group fails (skewed scalars), every record takes the binary search.
+  if (threadIdx.x < ntiles && len) {
+    const u32 t = threadIdx.x, first = t ? tmp[t - 1] : 0u, last = tmp[t] - 1;
+    u32 g1 = (u32)((float)first * tiles_per_record), g2 = (u32)((float)last * tiles_per_record);
+    if (g1 > ntiles - 1) g1 = ntiles - 1;
+    if (g2 > ntiles - 1) g2 = ntiles - 1;
+    if (g1 + 31 < t || t + 31 < g1 || g2 + 31 < t || t + 31 < g2) sh_far = 1;
+  }
+  __syncthreads();
+  const bool near = sh_far == 0 && tagmask != 0;
 #pragma unroll
   for (u32 it = 0; it < SORT20_CAP / 1024; it++) {
     const u32 e = it * 1024 + threadIdx.x;
     r[it] = 0;
     kk[it] = 0;
     if (e < m) {
-      const u32 x = stage[e];
-      // tile = first t with run_end[t] > e.  Uniform scalars give every tile the same share of the group, so
-      // e * ntiles / m is right to within a tile or two: a short walk from there (two or three LDS reads
-      // instead of a ten-step binary search per record), the search only when the walk does not arrive
-      // (skewed scalars)
-      u32 lo_t = (u32)((float)e * tiles_per_record);  // a guess: any value is corrected below
+      const u32 xt = stage[e], x = xt & ~tagmask;
+      u32 lo_t = (u32)((float)e * tiles_per_record);
       if (lo_t > ntiles - 1) lo_t = ntiles - 1;
-      u32 steps = 0;
-      while (lo_t > 0 && run_end[lo_t - 1] > e && steps < 6) { lo_t--; steps++; }
-      while (run_end[lo_t] <= e && lo_t < ntiles - 1 && steps < 6) { lo_t++; steps++; }
-      if (steps >= 6) {
+      if (near) {
+        u32 d = ((xt >> 26) - lo_t) & 63u;  // tile - guess mod 64, in [-32, 31]
+        lo_t += d;
+        if (d >= 32u) lo_t -= 64u;
+      } else {
         u32 hi_t = ntiles - 1;
         lo_t = 0;
         while (lo_t < hi_t) {

@@ -104,6 +104,26 @@ def test_skewed_scalars_take_the_split_path_and_recover(wide, orc, table):
     _check(wide, orc, h, uniform)
 
 
+def test_uneven_tiles_take_pass_b_search_path(wide, orc, table):
+    """Pass B (k_group_sort_tl) gets a record's tile back from six bits stored with it and a guess from its place
+    in the group, e * tiles / m -- valid while every run of the group lies within 31 tiles of the guess, which it
+    checks per run; otherwise every record of the group takes the binary search.  Zero scalars leave no records:
+    a call whose first 70 % are zero has its first record ~90 tiles away from the guess, and one with a sparse
+    first half and a dense second half drifts away from it gradually."""
+    import numpy as np
+    h, n = table
+    s = bytearray(orc.synth_scalars(0xC2A, n))
+    cut = (7 * n) // 10
+    s[:32 * cut] = bytes(32 * cut)
+    _check(wide, orc, h, bytes(s))
+    arr = np.frombuffer(orc.synth_scalars(0xC2B, n), dtype=np.uint8).reshape(n, 32).copy()
+    keep = np.ones(n, dtype=bool)
+    keep[: n // 2] = (np.arange(n // 2) % 5) == 0
+    arr[~keep] = 0
+    _check(wide, orc, h, arr.tobytes())
+    _check(wide, orc, h, orc.synth_scalars(0xC2C, n))  # and the tagged path again on the same context
+
+
 def test_repeated_scalars_chains_and_heavy_queue(wide, orc, table):
     """k_fix_boundary joins up to four partial sums of a bucket per lane; buckets that span 5..32 chunks go
     to the medium queue (serial chains by k_heavy's quads), longer ones to the heavy queue.  Scalars drawn
