@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-ms", type=int, default=150,
+                    help="blocking calls (discarded) for this long before the blocking-call legs; the W warm-up steps and "
+                         "the K timed steps follow those legs")
     ap.add_argument("--log2n", type=int, default=20, help="weak scaling: points per GPU = 2^log2n")
     ap.add_argument("--total-log2n", type=int, default=0, help="strong scaling: 2^T points over all GPUs")
     ap.add_argument("--window-bits", type=int, default=0)
@@ -211,19 +214,32 @@ def worker(args) -> int:
 
             return sharding.run_pipelined(steps, depth, submit, wait, ex, host_us)
 
-        def blocking_calls(self, calls, phase=None):
-            """`calls` strictly blocking steps (MSM, exchange, host sum), each timed on the host."""
+        def blocking_calls(self, calls, phases=None):
+            """`calls` strictly blocking steps (MSM, exchange, host sum), each timed on the host; `phases`
+            (a list) receives every call's phase times (bn256_last_timing: summed over the call's passes)."""
             ts, res = [], None
             for _ in range(calls):
                 t0 = time.perf_counter()
+                one = [0.0] * 7 if phases is not None else None
                 if ex is None:  # one GPU: the blocking entry point itself (bn256_msm_dev)
                     res = eng.msm_dev(self.bases, self.scalars.data_ptr(), self.n)
-                    if phase is not None:
-                        phase[:] = [a + b for a, b in zip(phase, eng.last_timing())]
+                    if one is not None:
+                        one[:] = eng.last_timing()
                 else:
-                    res = self.run(1, 1, phase)
+                    res = self.run(1, 1, one)
                 ts.append(time.perf_counter() - t0)
+                if phases is not None:
+                    phases.append(one)
             return ts, res
+
+        def settle(self, seconds):
+            """Blocking calls, discarded, for `seconds` of wall time: the chip needs ~0.1 s of sustained load before
+            its kernel times stop moving (tools/ab_warm.sh); returns the number of calls."""
+            k, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                self.blocking_calls(1)
+                k += 1
+            return k
 
         def timed(self, steps, depth):
             """barrier + synchronize on both sides, MAX over ranks; returns (seconds, last result)."""
@@ -248,28 +264,34 @@ def worker(args) -> int:
     # set-up (untimed, before the W warm-up steps): every lane allocates its workspaces; with an exchange,
     # enough steps for RCCL to finish its lazy channel set-up (the first collectives take milliseconds)
     wl.run(args.depth + (8 if use_dist else 0), args.depth)
-    wl.run(args.warmup, args.depth)
-    host_us[:] = [0.0] * 3
-    dt, result = wl.timed(args.steps, args.depth)
-    steps = max(args.steps, 1)
-    host_timed = [x / steps for x in host_us]
+    # Order of the legs: the blocking-call legs first, behind a settling period of their own, then the
+    # contract's W warm-up steps and its K timed steps.  The chip's kernel times keep falling for its first ~0.1 s
+    # of sustained load (tools/ab_warm.sh: the same 20 timed steps give 892-908 Mpts/s behind 5 warm-up steps and
+    # 930-942 behind 50); a step here is ~1 ms, so W = 5 is 6 ms.  With the timed region first, it and the blocking
+    # legs behind it both fell into that period at the driver's `--steps 20`.  Every rank runs the same sequence.
     # The same K steps as strictly blocking calls (not part of `value`), twice: first as a caller makes them
     # (`single_call`: wall time per call), then with the library's per-phase HIP events switched on
     # (bn256_ctx_set_phase_timing: the events cost 1-2.5 % of such a call, so they are off by default) for
     # `phases_ms` and the roofline's kernel time.  With several calls in flight an event pair would also span
-    # the time a kernel waits behind the other call's kernels, which is not kernel time.
-    phase = [0.0] * 7
-    nblk = max(args.steps, 10)
-    wl.run(2, 1)
+    # the time a kernel waits behind the other call's kernels, which is not kernel time.  Medians over the calls.
+    nblk = max(args.steps, 50)
+    settle_calls = wl.settle(args.settle_ms * 1e-3)
     sync()
     per_call, result_blocking = wl.blocking_calls(nblk)
     sync()
     dt_blocking = sum(per_call)
     eng.set_phase_timing(True)
     wl.blocking_calls(2)
-    wl.blocking_calls(nblk, phase)
+    per_phase = []
+    wl.blocking_calls(nblk, per_phase)
     eng.set_phase_timing(False)
     sync()
+    phase = [statistics.median(c[i] for c in per_phase) * nblk for i in range(7)]  # (x nblk: divided again below)
+    wl.run(args.warmup, args.depth)
+    host_us[:] = [0.0] * 3
+    dt, result = wl.timed(args.steps, args.depth)
+    steps = max(args.steps, 1)
+    host_timed = [x / steps for x in host_us]
 
     # who took part (N > 1 or the forced 1-rank rehearsal): every rank's device and its k_accumulate time,
     # all-gathered, so that the line itself shows that `world` DISTINCT GPUs ran the job
@@ -338,10 +360,13 @@ def worker(args) -> int:
                 "fixed_base_table": not args.no_precompute,
                 "parallelism": f"point-slices x{world}, RCCL all_gather of 64-byte partials ({args.depth} steps' worth per call), host sum",
                 "calls_in_flight": args.depth, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES") or 4),
+                "order": f"set-up (table, one call per lane); {settle_calls} discarded blocking calls ({args.settle_ms} ms); "
+                         f"{nblk} + {nblk} blocking calls (single_call, phases_ms / roofline); {args.warmup} warm-up steps; "
+                         f"{args.steps} timed steps; the other legs",
                 "setup_seconds_bases": wl.setup_s,
                 "result_xy": result.hex(),
             },
-            # per call, HIP events on the call's stream, over the blocking calls that follow the timed region
+            # per call (medians), HIP events on the call's stream, over the blocking calls before the warm-up steps
             "phases_ms": {"sort_pass_a": phase[0], "scan": phase[1], "sort_pass_b": phase[2], "accumulate": phase[3],
                           "fix": phase[4], "reduce": phase[5], "device_total": phase[6]},
             "host_us_per_step": {"submit": host_timed[0], "wait": host_timed[1], "exchange": host_timed[2]},
@@ -359,7 +384,7 @@ def worker(args) -> int:
                 "kernel_ms": phase[3],
                 "launches_per_call": launches,
                 "points_per_launch": n_launch,
-                "measured_over": f"{nblk} blocking calls after the timed region (one call on the chip at a time), "
+                "measured_over": f"median of {nblk} blocking calls before the warm-up steps, behind {settle_calls} discarded ones (one call on the chip at a time), "
                                  f"the library's HIP events on the call's own stream (switched on for these calls only)",
                 "achieved": achieved,
                 "peak": IMAD_PEAK,

@@ -36,7 +36,7 @@ ph, sc, rf = bench["phases_ms"], bench["single_call"], bench["roofline"]
 acc = pmc.get("k_accumulate<true>") or pmc["k_accumulate"]
 adds = acc["SQ_INSTS_VALU"] and 13 * n  # one mixed addition per (point, window), minus zero digits (2^-20 of them)
 L = []
-L.append(f"Source: `profiles/{tag}_bench_2p20.json` (the default `python3 bench.py --steps 50 --warmup 5` on one MI355X), "
+L.append(f"Source: `profiles/{tag}_bench_2p20.json` (`python3 bench.py --gpus 1 --steps {bench['steps']} --warmup {bench['warmup']}`, the driver's command, on one MI355X), "
          f"`profiles/{tag}_pmc_2p20.json`, `profiles/{tag}_rocprofv3_kernel_stats_bench_2p20*.csv`; regenerate with "
          f"`tools/refresh_profiles.sh` on the GPU box, then `tools/pmc_summary.py` and `tools/doc_numbers.py` here.")
 L.append("")

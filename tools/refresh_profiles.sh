@@ -7,7 +7,8 @@ set -e -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out
 rm -rf $O/prof_kt $O/prof_kt1 $O/pmc_fetch $O/pmc_write $O/pmc_grbm $O/pmc_sq1 $O/pmc_sq2
-timeout -k 10 300 python3 bench.py --steps 50 --warmup 5 > $O/bench_2p20.json 2> $O/bench_2p20.err
+# the driver's own command (BENCH_rNN.json: `python3 bench.py --gpus 1 --steps 20 --warmup 5`)
+timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_2p20.json 2> $O/bench_2p20.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -o kt -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 2 > $O/bench_kt.json 2> $O/bench_kt.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt1 -o kt -- python3 bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 2 --depth 1 > $O/bench_kt1.json 2> $O/bench_kt1.err
 B="python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 --depth 1"
