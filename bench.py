@@ -27,7 +27,9 @@ and their calls do not overlap (tools/probe/stream_probe.hip).
                      on one GPU, in eight passes)
 
 Besides `value` the line carries, measured in the same run: `single_call` (SURVEY 8d's wording of
-the metric: one blocking call, median), `pcie_inclusive` (scalars in host memory, never `value`),
+the metric: one blocking call, median; this leg and the phase-timed calls behind the roofline run BEFORE the
+warm-up steps, behind `--settle-ms` of discarded calls -- `config.order`), `pcie_inclusive`
+(scalars in host memory, never `value`),
 `bulletproofs_like` (the aL / aR scalar distribution), `n_2p24` (2^24 points on this one GPU) at
 N = 1, and `strong_2p24` (2^24 points over all ranks, with the same job on rank 0's GPU alone beside it:
 `efficiency_vs_n1`) at N > 1.  At N = 1 also the other BASELINE.json configs and the element-wise rows, each
