@@ -237,11 +237,15 @@ def worker(args) -> int:
         def settle(self, seconds):
             """Blocking calls, discarded, for `seconds` of wall time: the chip needs ~0.1 s of sustained load before
             its kernel times stop moving (tools/ab_warm.sh); returns the number of calls."""
-            k, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < seconds:
-                self.blocking_calls(1)
-                k += 1
-            return k
+            # the number of calls is agreed between the ranks (every call ends in a collective when N > 1): from
+            # the slowest rank's time for two calls
+            ts, _ = self.blocking_calls(2)
+            t = torch.tensor([max(min(ts), 1e-5)], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            k = max(0, min(2000, int(seconds / float(t.item())) - 2))
+            self.blocking_calls(k)
+            return k + 2
 
         def timed(self, steps, depth):
             """barrier + synchronize on both sides, MAX over ranks; returns (seconds, last result)."""
