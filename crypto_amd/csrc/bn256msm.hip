@@ -170,7 +170,7 @@ struct bn256_bases {
 };
 
 enum { WS_SCALARS, WS_RANK, WS_SKEY, WS_SVAL, WS_COUNTS, WS_OFFSETS, WS_BLOCKSUM, WS_BUCKETS, WS_PARTIALS,
-       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_PEER_A, WS_PEER_B, WS_SMTABLE, WS_COUNT };
+       WS_PACK, WS_TMP, WS_GATHER, WS_LASTB, WS_GBASE, WS_SUBHIST, WS_HEAVYTMP, WS_PEER_A, WS_PEER_B, WS_SMTABLE, WS_CHUNKB, WS_COUNT };
 
 struct bn256_ctx {
   int device;
@@ -1060,6 +1060,7 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   if ((rc = ws_reserve(ctx, WS_BUCKETS, nbt * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_PARTIALS, 2 * Tmax * sizeof(xyzz_mem)))) return rc;
   if ((rc = ws_reserve(ctx, WS_LASTB, Tmax * 4))) return rc;
+  if (two_pass && wide && (rc = ws_reserve(ctx, WS_CHUNKB, (Tmax + 8) * 4))) return rc;  // k_group_sort_tl's hints for k_accumulate
   if ((npack * 32 + 2) * 4 > ctx->h_pack_cap) return BN256_EINVAL;
 
   u32* counts = (u32*)ctx->ws[WS_COUNTS];
@@ -1177,7 +1178,7 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
       if (wide)
         hipLaunchKernelGGL(k_group_sort_tl, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
                            (const u32*)gtotal, nt2, (u32)((n_ch + SORT2_TILE - 1) / SORT2_TILE), (u32)nbt, LB2, NH2, (u32)off_ch,
-                           (u32)stride, (u32)b->n, offsets, sval, buckets, init_inf, oversized);
+                           (u32)stride, (u32)b->n, offsets, sval, buckets, init_inf, oversized, K, (u32*)ctx->ws[WS_CHUNKB]);
       else
         hipLaunchKernelGGL(k_group_sort, dim3(G2), dim3(1024), lds_gsort, s, (const u32*)rank, (const u32*)loc,
                            (const u32*)gtotal, nt2, (u32)nbt, LB2, NH2, ibits, (u32)off_ch, (u32)stride, (u32)b->n, offsets,
@@ -1254,12 +1255,15 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
       prio_steps = at(a) | (at(bq) << 8) | (at(cq) << 16);
 
     }
+    const u32* chunk_hint = two && wide ? (const u32*)ctx->ws[WS_CHUNKB] : (const u32*)nullptr;
     if (b->no_inf)
       hipLaunchKernelGGL(k_accumulate<true>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb, prio_steps);
+                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb, prio_steps,
+                         chunk_hint);
     else
       hipLaunchKernelGGL(k_accumulate<false>, dim3(nblocks(T, 128)), dim3(128), 0, s, (const aff_mem*)b->d, (const u32*)sval,
-                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb, prio_steps);
+                         (const u32*)offsets, (u32)nbt, K, add_prev, buckets, partials, (const u32*)d_flags, lastb, prio_steps,
+                         chunk_hint);
     MSM_MARK(4);
     if (by_chunks)
       hipLaunchKernelGGL(k_fix_boundary, dim3(nblocks(std::min<size_t>(T, 262144), 256)), dim3(256), 0, s,

@@ -572,7 +572,8 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
                                                         u32 nbt, u32 LB, u32 NH, u32 base_off, u32 pt_stride,
                                                         u32 level_stride, u32* __restrict__ offsets,
                                                         u32* __restrict__ sval, xyzz_mem* __restrict__ buckets,
-                                                        u32 init_inf, u32* __restrict__ flags) {
+                                                        u32 init_inf, u32* __restrict__ flags, u32 K,
+                                                        u32* __restrict__ chunk_bucket) {
   SORT_KERNEL_PRIO();
   // ntiles: tiles of pass A (a multiple of SORT2_S, the last ones may be empty); ntiles_data: those with scalars
   extern __shared__ u32 lds[];
@@ -696,6 +697,14 @@ __global__ void __launch_bounds__(1024) k_group_sort_tl(const u32* __restrict__ 
     cur[threadIdx.x] = excl;
     offsets[g * B + threadIdx.x] = gs + excl;
     if (init_inf && t == 0) xyzz_mem_set_inf(&buckets[g * B + threadIdx.x]);
+    // k_accumulate's chunk j starts at entry j K: the bucket that holds that entry, as a hint (the kernel checks
+    // it against offsets[] and searches when it does not fit -- chunks inside a bucket of more than four chunks,
+    // the split-sort path, anything stale)
+    if (chunk_bucket && t) {
+      const u32 o = gs + excl;
+      u32 j = (o + K - 1) / K;
+      for (u32 k = 0; k < 4 && (u64)j * K < (u64)o + t; k++, j++) chunk_bucket[j] = g * B + threadIdx.x;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -967,7 +976,8 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
                                                     const u32* __restrict__ offsets, u32 nbt, u32 K, u32 add_prev,
                                                     xyzz_mem* __restrict__ buckets,
                                                     xyzz_mem* __restrict__ partials, const u32* __restrict__ flags,
-                                                    u32* __restrict__ lastb, u32 prio_steps) {
+                                                    u32* __restrict__ lastb, u32 prio_steps,
+                                                    const u32* __restrict__ chunk_bucket) {
   // an oversized group that no split kernel handled left part of sval[] unwritten: do not gather through
   // it (the host repeats the call with the split kernels, msm_finish)
   if (flags[0] & MSM_FLAG_OVERSIZED) return;
@@ -977,8 +987,17 @@ __global__ void __launch_bounds__(256) k_accumulate(const aff_mem* __restrict__ 
   if (start64 >= M) return;
   u32 start = (u32)start64;
   u32 end = (M - start > K) ? start + K : M;
-  // cur = the bucket containing entry `start`: first b with offsets[b+1] > start
+  // cur = the bucket containing entry `start`: first b with offsets[b+1] > start.  The two-pass sort leaves it
+  // as a hint (k_group_sort_tl); nineteen dependent loads of a binary search otherwise -- every wave of the
+  // kernel's single round stands in them at once, nothing to hide them behind
   u32 lo = 0, hi = nbt - 1;
+  if (chunk_bucket) {
+    const u32 h = chunk_bucket[t];
+    if (h < nbt) {
+      const u32 ob = offsets[h], oe = offsets[h + 1];
+      if (ob <= start && start < oe) lo = hi = h;
+    }
+  }
   while (lo < hi) {
     u32 mid = (lo + hi) >> 1;
     if (offsets[mid + 1] <= start) lo = mid + 1; else hi = mid;
