@@ -893,12 +893,11 @@ static int msm_enqueue_srcs_impl(bn256_ctx* ctx, const msm_src* srcs, int nsrc, 
   pend->empty = true;
   for (float& f : ctx->last_ms) f = 0.f;
   const bn256_bases* b0 = nullptr;
-  size_t n_total = 0, n_single = 0;
+  size_t n_single = 0;
   int live = 0;
   for (int i = 0; i < nsrc; i++) {
     if (!srcs[i].n) continue;
     if (!b0) b0 = srcs[i].b;
-    n_total += srcs[i].n;
     n_single = srcs[i].n;
     live++;
   }
