@@ -442,8 +442,8 @@ def worker(args) -> int:
         # 2^24 points in all (configs[4]'s job): on this GPU at N = 1, sliced over the ranks at N > 1
         wl.free()
         big = Workload(1 << 24, True)
-        big.run(2, args.depth)
-        ksteps = 6
+        big.run(args.depth, args.depth)
+        ksteps = 12  # 0.2 s at N = 1 (six steps moved by 5 % from run to run)
         dtb, resb = big.timed(ksteps, args.depth)
         big.run(2, 1)
         sync()
